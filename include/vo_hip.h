@@ -1,0 +1,145 @@
+/* vo_hip.h -- C ABI of libvo_hip.so, the MI355X (gfx950) implementation of the
+ * visual-odometry front-end hot path: gray -> FAST-9/16 + NMS -> top-N ->
+ * 7x7 blur -> rBRIEF-256 -> Hamming kNN-2 -> ratio test -> fundamental-matrix
+ * RANSAC filter -> motion filter -> depth back-projection -> PnP RANSAC pose.
+ *
+ * Every entry point replaces one call the reference makes into OpenCV (the
+ * reference's own code is glue around those calls); the reference file:line of
+ * the call site is cited at each declaration.  All arguments are plain
+ * pointers and sizes.  Unless stated otherwise a data pointer may address host
+ * memory or device memory of the context's GPU (copies use hipMemcpyDefault).
+ *
+ * Conventions
+ *  - every function returns VO_OK (0) or a negative VO_ERR_* code and never
+ *    throws; vo_last_error() returns a message for the last failure;
+ *  - a vo_ctx is bound to one GPU and one HIP stream and is not re-entrant:
+ *    one context per camera stream / caller thread, like one FrameProcessor in
+ *    the reference (reference src/vo_node.cpp:940-962);
+ *  - there is no CPU fallback: if the GPU or the code object is unusable,
+ *    vo_create() fails.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_OK 0
+#define VO_ERR_ARG (-1)         /* bad argument / size beyond the context limits */
+#define VO_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define VO_ERR_STATE (-3)       /* call order violated */
+#define VO_ERR_UNSUPPORTED (-4) /* documented gap */
+
+#define VO_MAX_FEATURES_LIMIT 6144 /* hard upper bound of vo_cfg.max_features */
+
+typedef struct vo_ctx vo_ctx;
+
+/* cv::KeyPoint as a POD: pt.x, pt.y, size, angle, response, octave. */
+typedef struct {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+} vo_kp;
+
+/* the two nearest train descriptors of one query (idx -1 when absent) */
+typedef struct {
+    int32_t idx0, dist0;
+    int32_t idx1, dist1;
+} vo_knn2;
+
+/* one cv::DMatch(queryIdx, trainIdx, distance) plus both image points */
+typedef struct {
+    int32_t query, train;
+    float distance;
+    float px, py; /* point in the previous (query) frame */
+    float cx, cy; /* point in the current (train) frame  */
+} vo_match;
+
+typedef struct {
+    int max_width, max_height; /* largest frame, width*height <= 2^24 */
+    int max_features;          /* largest keypoint budget per frame */
+    int max_batch;             /* largest number of frames per vo_batch_run */
+    /* BGR->gray fixed-point weights; all 0 selects OpenCV 4.x's
+     * (3735, 19235, 9798) >> 15 */
+    int gray_b, gray_g, gray_r, gray_shift;
+} vo_cfg;
+
+/* ---- context -------------------------------------------------------- */
+
+/* One context = one camera stream's device state (buffers, HIP stream). Takes
+ * the place of constructing FeatureDetector / FeatureMatcher / FrameProcessor
+ * (reference src/vo_node.cpp:79-80,170-173).  Returns NULL on failure (see
+ * vo_last_error(NULL)). */
+vo_ctx *vo_create(int device, const vo_cfg *cfg);
+void vo_destroy(vo_ctx *ctx);
+const char *vo_last_error(const vo_ctx *ctx);
+/* library/ABI version, bumped on incompatible change */
+int vo_abi_version(void);
+
+/* ---- single-frame operators (synchronous) --------------------------- */
+
+/* cv::cvtColor(src, dst, COLOR_BGR2GRAY) for 8-bit BGR (channels 3) or BGRA
+ * (channels 4).  reference src/frame_processor.cpp:204-208, :223,
+ * src/feature_detector.cpp:46, src/image_processor.cpp:35 */
+int vo_gray(vo_ctx *ctx, const uint8_t *src, int width, int height,
+            int src_stride, int channels, uint8_t *dst, int dst_stride);
+
+/* The per-pixel half of cv::FAST(gray, kps, threshold, true): FAST-9/16 corner
+ * score of every pixel, 0 where the segment test fails.  Diagnostic view of
+ * the detector's first kernel.  reference src/feature_detector.cpp:59 */
+int vo_fast_score(vo_ctx *ctx, const uint8_t *gray, int width, int height,
+                  int stride, int threshold, uint8_t *score, int score_stride);
+
+/* The smoothing cv::ORB::compute applies before sampling descriptors:
+ * GaussianBlur 7x7, sigma 2, BORDER_REFLECT_101 in 8-bit fixed point.
+ * reference src/feature_detector.cpp:73 */
+int vo_blur7(vo_ctx *ctx, const uint8_t *gray, int width, int height,
+             int stride, uint8_t *dst, int dst_stride);
+
+/* FeatureDetector::detectFeatures(gray, max_features, fast_threshold) on a
+ * 1-channel frame: cv::FAST with non-max suppression, keep the max_features
+ * strongest, cv::ORB::compute (border filter 31 px, blur, rBRIEF-256).
+ * reference src/feature_detector.cpp:37-88
+ * When more than max_features corners exist they are ordered by (response
+ * descending, raster index ascending); otherwise raster order is kept.
+ * kps must hold max_features entries, desc 32*max_features bytes. */
+int vo_detect(vo_ctx *ctx, const uint8_t *gray, int width, int height,
+              int stride, int max_features, int fast_threshold, vo_kp *kps,
+              uint8_t *desc, int *n_out);
+
+/* cv::BFMatcher(NORM_HAMMING, false).knnMatch(query, train, k = 2) on
+ * 256-bit descriptors; equal distances keep the lower train index first.
+ * reference src/feature_matcher.cpp:27-31 */
+int vo_knn2_hamming(vo_ctx *ctx, const uint8_t *query, int n_query,
+                    const uint8_t *train, int n_train, vo_knn2 *out);
+
+/* cv::findFundamentalMat(p1, p2, FM_RANSAC, threshold, confidence, mask)
+ * with max_iters (OpenCV default 1000) and cv::RNG seed 2^64-1.
+ * p1, p2: n x 2 float32; mask: n bytes; F: 9 doubles row-major.
+ * *found is 0 when no model with more than 6 inliers exists (mask all 0).
+ * Fewer than 15 points (OpenCV's LMedS branch) -> VO_ERR_UNSUPPORTED.
+ * reference src/feature_matcher.cpp:52-58 */
+int vo_find_fundamental_ransac(vo_ctx *ctx, const float *p1, const float *p2,
+                               int n, double threshold, double confidence,
+                               int max_iters, uint8_t *mask, double *F,
+                               int *found, int *iters_run);
+
+/* FeatureMatcher::match(prev, curr, ., .): kNN-2, Lowe ratio (float32),
+ * F-RANSAC mask (3.0 px, 0.99), motion < 100 px.  Query = prev, train = curr.
+ * out must hold n_prev entries.  An empty result (fewer than 8 ratio
+ * survivors, or no RANSAC model) returns VO_OK with *n_out = 0.
+ * reference src/feature_matcher.cpp:15-104 */
+int vo_match_features(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev_desc,
+             int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
+             int n_curr, float ratio, vo_match *out, int *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_HIP_H */

@@ -1,0 +1,216 @@
+"""ctypes front end of the CPU oracle (oracle/libvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The shipped package never imports this module.
+PARITY UNPINNED -- see vo_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvo_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+KNN_DTYPE = np.dtype([("idx0", "<i4"), ("dist0", "<i4"), ("idx1", "<i4"), ("dist1", "<i4")])
+MATCH_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("distance", "<f4"),
+                        ("px", "<f4"), ("py", "<f4"), ("cx", "<f4"), ("cy", "<f4")])
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvo_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ora_rng_next.restype = C.c_uint32
+        _lib.ora_find_fundamental_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                                     C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]
+        _lib.ora_backproject.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        _lib.ora_solve_pnp_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                              C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_pnp_iterative.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        _lib.ora_match_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gray(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img)
+    h, w, cn = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_gray(_p(img), w, h, w * cn, cn, _p(out), w)
+    return out
+
+
+def fast_score_map(g: np.ndarray, thr: int) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_fast_score_map(_p(g), w, h, w, thr, _p(out), w)
+    return out
+
+
+def fast(g: np.ndarray, thr: int) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    cap = (w * h) // 4 + 16
+    out = np.zeros(cap, KP_DTYPE)
+    n = lib().ora_fast(_p(g), w, h, w, thr, _p(out), cap)
+    return out[:n].copy()
+
+
+def blur7(g: np.ndarray) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_blur7(_p(g), w, h, w, _p(out), w)
+    return out
+
+
+def brief(blur: np.ndarray, kps: np.ndarray) -> np.ndarray:
+    blur = np.ascontiguousarray(blur)
+    kps = np.ascontiguousarray(kps)
+    h, w = blur.shape
+    out = np.zeros((len(kps), 32), np.uint8)
+    lib().ora_brief(_p(blur), w, h, w, _p(kps), len(kps), _p(out))
+    return out
+
+
+def detect(g: np.ndarray, max_features: int = 1000, fast_threshold: int = 20):
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    kps = np.zeros(max(max_features, 1), KP_DTYPE)
+    desc = np.zeros((max(max_features, 1), 32), np.uint8)
+    n = lib().ora_detect(_p(g), w, h, w, max_features, fast_threshold, _p(kps), _p(desc))
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def knn2(q: np.ndarray, t: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(q)
+    t = np.ascontiguousarray(t)
+    out = np.zeros(len(q), KNN_DTYPE)
+    lib().ora_knn2_hamming(_p(q), len(q), _p(t), len(t), _p(out))
+    return out
+
+
+def ratio_test(knn, nt, ratio, qk, tk):
+    out = np.zeros(max(len(knn), 1), MATCH_DTYPE)
+    n = lib().ora_ratio_test(_p(knn), len(knn), nt, ratio, _p(qk), _p(tk), _p(out))
+    return out[:n].copy()
+
+
+def rng_stream(n: int, seed: int = 0xFFFFFFFFFFFFFFFF) -> np.ndarray:
+    class R(C.Structure):
+        _fields_ = [("state", C.c_uint64)]
+    r = R(seed)
+    return np.array([lib().ora_rng_next(C.byref(r)) for _ in range(n)], np.uint32)
+
+
+def f7(m1: np.ndarray, m2: np.ndarray) -> np.ndarray:
+    m1 = np.ascontiguousarray(m1, np.float32)
+    m2 = np.ascontiguousarray(m2, np.float32)
+    out = np.zeros((3, 9), np.float64)
+    n = lib().ora_f7(_p(m1), _p(m2), _p(out))
+    return out[:max(n, 0)].copy()
+
+
+def f_error(p1, p2, F):
+    p1 = np.ascontiguousarray(p1, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    F = np.ascontiguousarray(F, np.float64)
+    err = np.zeros(len(p1), np.float32)
+    lib().ora_f_error(_p(p1), _p(p2), len(p1), _p(F), _p(err))
+    return err
+
+
+def find_fundamental_ransac(p1, p2, thr=3.0, conf=0.99, max_iters=1000):
+    p1 = np.ascontiguousarray(p1, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    n = len(p1)
+    mask = np.zeros(max(n, 1), np.uint8)
+    F = np.zeros(9, np.float64)
+    iters = C.c_int(0)
+    ok = lib().ora_find_fundamental_ransac(_p(p1), _p(p2), n, thr, conf, max_iters, _p(mask),
+                                           _p(F), C.addressof(iters))
+    return bool(ok), F.reshape(3, 3), mask[:n].copy(), iters.value
+
+
+def match_filter(knn, nt, qk, tk, ratio=0.7):
+    nq = len(knn)
+    out = np.zeros(max(nq, 1), MATCH_DTYPE)
+    mask = np.zeros(max(nq, 1), np.uint8)
+    nr = C.c_int(0)
+    n = lib().ora_match_filter(_p(knn), nq, nt, _p(qk), _p(tk), ratio, _p(out), _p(mask),
+                               C.addressof(nr))
+    return out[:n].copy(), mask[:nr.value].copy(), nr.value
+
+
+def backproject(matches, depth, fx, fy, cx, cy):
+    m = np.ascontiguousarray(matches).copy()
+    depth = np.ascontiguousarray(depth, np.float32)
+    h, w = depth.shape
+    pts3 = np.zeros((max(len(m), 1), 3), np.float32)
+    n = lib().ora_backproject(_p(m), len(m), _p(depth), w, h, w, fx, fy, cx, cy, _p(pts3))
+    if n == 0:
+        return m, pts3[:0].copy()
+    return m[:n].copy(), pts3[:n].copy()
+
+
+def track_filter(matches, prev_age, n_curr):
+    m = np.ascontiguousarray(matches).copy()
+    prev_age = np.ascontiguousarray(prev_age, np.int32)
+    curr_age = np.zeros(max(n_curr, 1), np.int32)
+    n = lib().ora_track_filter(_p(m), len(m), _p(prev_age), len(prev_age), _p(curr_age), n_curr)
+    return m[:n].copy(), curr_age[:n_curr].copy()
+
+
+def solve_pnp_ransac(obj, img, fx, fy, cx, cy, iters=100, thr=8.0, conf=0.99):
+    obj = np.ascontiguousarray(obj, np.float32)
+    img = np.ascontiguousarray(img, np.float32)
+    n = len(obj)
+    rvec = np.zeros(3)
+    tvec = np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    ninl = C.c_int(0)
+    ok = lib().ora_solve_pnp_ransac(_p(obj), _p(img), n, fx, fy, cx, cy, iters, thr, conf,
+                                    _p(rvec), _p(tvec), _p(inl), C.addressof(ninl))
+    return bool(ok), rvec, tvec, inl[:ninl.value].copy()
+
+
+def rodrigues(v):
+    v = np.ascontiguousarray(v, np.float64)
+    if v.size == 3:
+        R = np.zeros(9)
+        lib().ora_rodrigues_vec2mat(_p(v), _p(R))
+        return R.reshape(3, 3)
+    r = np.zeros(3)
+    lib().ora_rodrigues_mat2vec(_p(v.reshape(9)), _p(r))
+    return r

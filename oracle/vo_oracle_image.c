@@ -1,0 +1,385 @@
+/* CPU oracle, image stages and matcher.  TEST INFRASTRUCTURE ONLY -- see
+ * vo_oracle.h.  PARITY UNPINNED (no OpenCV here, no reference test vectors).
+ */
+#include "vo_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/vo_orb_pattern.h"
+
+static inline int ora_cv_round(double v) { return (int)lrint(v); }
+
+/* ------------------------------------------------------------------ gray */
+
+/* [OCV-recall] OpenCV 4.x RGB2Gray<uchar>: 15-bit coefficients
+ * B 3735, G 19235, R 9798 (sum 32768), rounded descale.
+ * reference call sites: src/frame_processor.cpp:206, :223,
+ * src/feature_detector.cpp:46, src/image_processor.cpp:35 */
+void ora_gray(const uint8_t *src, int w, int h, int stride, int cn,
+              uint8_t *dst, int dstride)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = src + (size_t)y * stride;
+        uint8_t *d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++, s += cn)
+            d[x] = (uint8_t)((s[0] * 3735 + s[1] * 19235 + s[2] * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+/* ------------------------------------------------------------------ FAST */
+
+/* [OCV-recall] radius-3 Bresenham circle, OpenCV order */
+static const int fast_dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+static const int fast_dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+/* [OCV-recall] cornerScore<16> of fast_score.cpp: largest threshold for which
+ * the pixel still passes the 9-of-16 segment test. */
+static int fast_corner_score(const uint8_t *p, const int *off, int threshold)
+{
+    int d[25];
+    int v = p[0];
+    for (int k = 0; k < 25; k++) d[k] = v - p[off[k]];
+
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = d[k + 1] < d[k + 2] ? d[k + 1] : d[k + 2];
+        if (d[k + 3] < a) a = d[k + 3];
+        if (a <= a0) continue;
+        for (int j = 4; j <= 8; j++)
+            if (d[k + j] < a) a = d[k + j];
+        int t = a < d[k] ? a : d[k];
+        if (t > a0) a0 = t;
+        t = a < d[k + 9] ? a : d[k + 9];
+        if (t > a0) a0 = t;
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = d[k + 1] > d[k + 2] ? d[k + 1] : d[k + 2];
+        for (int j = 3; j <= 5; j++)
+            if (d[k + j] > b) b = d[k + j];
+        if (b >= b0) continue;
+        for (int j = 6; j <= 8; j++)
+            if (d[k + j] > b) b = d[k + j];
+        int t = b > d[k] ? b : d[k];
+        if (t < b0) b0 = t;
+        t = b > d[k + 9] ? b : d[k + 9];
+        if (t < b0) b0 = t;
+    }
+    return -b0 - 1;
+}
+
+/* [OCV-recall] FAST_t<16>: a pixel is a corner when more than 8 contiguous
+ * ring pixels are all brighter than v+t or all darker than v-t. */
+static int fast_is_corner(const uint8_t *p, const int *off, int t)
+{
+    int v = p[0];
+    int cb = v + t, c_b = v - t;
+    /* walk the 25-entry wrapped ring counting runs */
+    int run_b = 0, run_d = 0;
+    for (int k = 0; k < 25; k++) {
+        int x = p[off[k]];
+        if (x > cb) { if (++run_b > 8) return 1; } else run_b = 0;
+        if (x < c_b) { if (++run_d > 8) return 1; } else run_d = 0;
+    }
+    return 0;
+}
+
+void ora_fast_score_map(const uint8_t *img, int w, int h, int stride, int thr,
+                        uint8_t *score, int sstride)
+{
+    int off[25];
+    if (thr < 0) thr = 0;
+    if (thr > 255) thr = 255;
+    for (int k = 0; k < 25; k++) off[k] = fast_dy[k & 15] * stride + fast_dx[k & 15];
+    for (int y = 0; y < h; y++) memset(score + (size_t)y * sstride, 0, (size_t)w);
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t *row = img + (size_t)y * stride;
+        uint8_t *srow = score + (size_t)y * sstride;
+        for (int x = 3; x < w - 3; x++) {
+            const uint8_t *p = row + x;
+            /* high-speed reject on the four compass points */
+            int v = p[0];
+            int hi = v + thr, lo = v - thr;
+            int p0 = p[off[0]], p8 = p[off[8]];
+            if (!((p0 > hi || p8 > hi) || (p0 < lo || p8 < lo))) continue;
+            if (fast_is_corner(p, off, thr))
+                srow[x] = (uint8_t)fast_corner_score(p, off, thr);
+        }
+    }
+}
+
+int ora_fast(const uint8_t *img, int w, int h, int stride, int thr,
+             ora_kp *out, int cap)
+{
+    if (w < 7 || h < 7) return 0;
+    uint8_t *score = (uint8_t *)malloc((size_t)w * h);
+    ora_fast_score_map(img, w, h, stride, thr, score, w);
+    int n = 0;
+    /* [OCV-recall] corners live in x,y in [3, dim-4]; a corner is kept when
+     * its score is strictly greater than all 8 neighbours (non-corners = 0). */
+    for (int y = 3; y < h - 3; y++) {
+        const uint8_t *c = score + (size_t)y * w;
+        const uint8_t *u = c - w, *d = c + w;
+        for (int x = 3; x < w - 3; x++) {
+            int s = c[x];
+            if (!s) continue;
+            if (s > u[x - 1] && s > u[x] && s > u[x + 1] && s > c[x - 1] &&
+                s > c[x + 1] && s > d[x - 1] && s > d[x] && s > d[x + 1]) {
+                if (n < cap) {
+                    out[n].x = (float)x;
+                    out[n].y = (float)y;
+                    out[n].size = 7.f;
+                    out[n].angle = -1.f;
+                    out[n].response = (float)s;
+                    out[n].octave = 0;
+                }
+                n++;
+            }
+        }
+    }
+    free(score);
+    return n;
+}
+
+/* ---------------------------------------------------------------- select */
+
+static int g_sel_w;
+static int cmp_resp_desc_raster_asc(const void *pa, const void *pb)
+{
+    const ora_kp *a = (const ora_kp *)pa, *b = (const ora_kp *)pb;
+    if (a->response != b->response) return a->response > b->response ? -1 : 1;
+    long ra = (long)a->y * g_sel_w + (long)a->x;
+    long rb = (long)b->y * g_sel_w + (long)b->x;
+    return ra < rb ? -1 : (ra > rb ? 1 : 0);
+}
+
+int ora_select_top(ora_kp *kps, int n, int w, int max_features)
+{
+    if (n <= max_features) return n;
+    g_sel_w = w;
+    qsort(kps, (size_t)n, sizeof(ora_kp), cmp_resp_desc_raster_asc);
+    return max_features;
+}
+
+int ora_border_filter(ora_kp *kps, int n, int w, int h, int border)
+{
+    if (w <= border * 2 || h <= border * 2) return 0;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        float x = kps[i].x, y = kps[i].y;
+        if (x >= (float)border && x < (float)(w - border) && y >= (float)border &&
+            y < (float)(h - border))
+            kps[m++] = kps[i];
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------ blur */
+
+static inline int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+/* [OCV-recall] GaussianBlur(7x7, sigma 2) on CV_8U through the integer
+ * sepFilter2D path: float kernel from getGaussianKernel scaled by 256 and
+ * rounded (sum 257, not renormalised); rows accumulate in int32; columns add
+ * 2^15 and shift by 16 with saturation. */
+void ora_blur7(const uint8_t *src, int w, int h, int stride, uint8_t *dst,
+               int dstride)
+{
+    static const int kq[7] = {18, 34, 49, 55, 49, 34, 18};
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = src + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int k = -3; k <= 3; k++) acc += kq[k + 3] * s[reflect101(x + k, w)];
+            tmp[(size_t)y * w + x] = acc;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t *d = dst + (size_t)y * dstride;
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int k = -3; k <= 3; k++)
+                acc += kq[k + 3] * tmp[(size_t)reflect101(y + k, h) * w + x];
+            int v = (acc + (1 << 15)) >> 16;
+            d[x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+    free(tmp);
+}
+
+/* ----------------------------------------------------------------- BRIEF */
+
+/* [OCV-recall] computeOrbDescriptors, WTA_K = 2 */
+void ora_brief(const uint8_t *blur, int w, int h, int stride,
+               const ora_kp *kps, int n, uint8_t *desc)
+{
+    (void)w; (void)h;
+    for (int i = 0; i < n; i++) {
+        float angle = kps[i].angle;
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        float a = (float)cos(angle), b = (float)sin(angle);
+        const uint8_t *center = blur + (size_t)ora_cv_round(kps[i].y) * stride +
+                                ora_cv_round(kps[i].x);
+        uint8_t *d = desc + (size_t)i * 32;
+        for (int byte = 0; byte < 32; byte++) {
+            int val = 0;
+            for (int bit = 0; bit < 8; bit++) {
+                const signed char *p = vo_orb_bit_pattern_31 + (byte * 8 + bit) * 4;
+                float x0 = p[0] * a - p[1] * b, y0 = p[0] * b + p[1] * a;
+                float x1 = p[2] * a - p[3] * b, y1 = p[2] * b + p[3] * a;
+                int t0 = center[ora_cv_round(y0) * stride + ora_cv_round(x0)];
+                int t1 = center[ora_cv_round(y1) * stride + ora_cv_round(x1)];
+                val |= (t0 < t1) << bit;
+            }
+            d[byte] = (uint8_t)val;
+        }
+    }
+}
+
+/* reference src/feature_detector.cpp:37-88 on a 1-channel input */
+int ora_detect(const uint8_t *gray, int w, int h, int stride, int max_features,
+               int fast_threshold, ora_kp *kps, uint8_t *desc)
+{
+    int cap = (w * h) / 4 + 16;
+    ora_kp *all = (ora_kp *)malloc(sizeof(ora_kp) * (size_t)cap);
+    int n = ora_fast(gray, w, h, stride, fast_threshold, all, cap);
+    if (n > cap) n = cap;
+    n = ora_select_top(all, n, w, max_features);
+    if (n > 0) {
+        /* ORB::compute: border filter, blur level 0, sample the pattern */
+        n = ora_border_filter(all, n, w, h, 31);
+        if (n > 0) {
+            uint8_t *blur = (uint8_t *)malloc((size_t)w * h);
+            ora_blur7(gray, w, h, stride, blur, w);
+            ora_brief(blur, w, h, w, all, n, desc);
+            free(blur);
+        }
+    }
+    memcpy(kps, all, sizeof(ora_kp) * (size_t)n);
+    free(all);
+    return n;
+}
+
+/* --------------------------------------------------------------- matcher */
+
+/* [OCV-recall] batchDistance with K = 2: a candidate enters when its distance
+ * is strictly smaller than the current K-th best, so equal distances keep the
+ * lower train index first. */
+void ora_knn2_hamming(const uint8_t *q, int nq, const uint8_t *t, int nt,
+                      ora_knn2 *out)
+{
+    for (int i = 0; i < nq; i++) {
+        const uint64_t *a = (const uint64_t *)(q + (size_t)i * 32);
+        uint64_t a0, a1, a2, a3;
+        memcpy(&a0, a, 8); memcpy(&a1, a + 1, 8); memcpy(&a2, a + 2, 8); memcpy(&a3, a + 3, 8);
+        int d0 = 1 << 30, d1 = 1 << 30, i0 = -1, i1 = -1;
+        for (int j = 0; j < nt; j++) {
+            uint64_t b0, b1, b2, b3;
+            const uint8_t *bp = t + (size_t)j * 32;
+            memcpy(&b0, bp, 8); memcpy(&b1, bp + 8, 8); memcpy(&b2, bp + 16, 8); memcpy(&b3, bp + 24, 8);
+            int d = __builtin_popcountll(a0 ^ b0) + __builtin_popcountll(a1 ^ b1) +
+                    __builtin_popcountll(a2 ^ b2) + __builtin_popcountll(a3 ^ b3);
+            if (d < d1) {
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            }
+        }
+        out[i].idx0 = i0; out[i].dist0 = i0 >= 0 ? d0 : 0;
+        out[i].idx1 = i1; out[i].dist1 = i1 >= 0 ? d1 : 0;
+    }
+}
+
+int ora_ratio_test(const ora_knn2 *knn, int nq, int nt, float ratio,
+                   const ora_kp *qk, const ora_kp *tk, ora_match *out)
+{
+    int m = 0;
+    if (nt < 2) return 0; /* knn_match.size() < 2 -> skipped */
+    for (int i = 0; i < nq; i++) {
+        float d0 = (float)knn[i].dist0, d1 = (float)knn[i].dist1;
+        if (d0 < ratio * d1) {
+            out[m].query = i;
+            out[m].train = knn[i].idx0;
+            out[m].distance = d0;
+            out[m].px = qk[i].x; out[m].py = qk[i].y;
+            out[m].cx = tk[knn[i].idx0].x; out[m].cy = tk[knn[i].idx0].y;
+            m++;
+        }
+    }
+    return m;
+}
+
+int ora_cross_check(const ora_knn2 *fwd, int nq, const ora_knn2 *bwd, int nt,
+                    uint8_t *keep)
+{
+    int m = 0;
+    for (int i = 0; i < nq; i++) {
+        int j = fwd[i].idx0;
+        keep[i] = (uint8_t)(j >= 0 && j < nt && bwd[j].idx0 == i);
+        m += keep[i];
+    }
+    return m;
+}
+
+/* --------------------------------------------------- frame-processor glue */
+
+int ora_backproject(ora_match *m, int n, const float *depth, int w, int h,
+                    int dstride, double fx, double fy, double cx, double cy,
+                    float *pts3)
+{
+    const float min_depth = 50.0f, max_depth = 20000.0f;
+    ora_match *tmp = (ora_match *)malloc(sizeof(ora_match) * (size_t)(n > 0 ? n : 1));
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        float ptx = m[i].cx, pty = m[i].cy;
+        int u = (int)roundf(ptx), v = (int)roundf(pty);
+        if (u < 0 || u >= w || v < 0 || v >= h) continue;
+        float z = depth[(size_t)v * dstride + u];
+        if (isnan(z) || isinf(z) || z <= 0.0f || z < min_depth || z > max_depth) continue;
+        float X = (float)((ptx - cx) * z / fx);
+        float Y = (float)((pty - cy) * z / fy);
+        tmp[k] = m[i];
+        pts3[3 * k + 0] = X; pts3[3 * k + 1] = Y; pts3[3 * k + 2] = z;
+        k++;
+    }
+    if (k > 0) memcpy(m, tmp, sizeof(ora_match) * (size_t)k);
+    free(tmp);
+    return k;
+}
+
+int ora_track_filter(ora_match *m, int n, const int32_t *prev_age, int n_prev,
+                     int32_t *curr_age, int n_curr)
+{
+    const int min_track_length = 3;
+    for (int i = 0; i < n_curr; i++) curr_age[i] = 0;
+    for (int i = 0; i < n; i++) {
+        int pa = (m[i].query >= 0 && m[i].query < n_prev) ? prev_age[m[i].query] : 0;
+        if (m[i].train >= 0 && m[i].train < n_curr) curr_age[m[i].train] = pa + 1;
+    }
+    if (n > 80) {
+        int mature = 0;
+        for (int i = 0; i < n; i++) {
+            int t = m[i].train;
+            if (t >= 0 && t < n_curr && curr_age[t] >= min_track_length) mature++;
+        }
+        if (mature >= 50) {
+            int k = 0;
+            for (int i = 0; i < n; i++) {
+                int t = m[i].train;
+                if (t >= 0 && t < n_curr && curr_age[t] >= min_track_length) m[k++] = m[i];
+            }
+            return k;
+        }
+    }
+    return n;
+}

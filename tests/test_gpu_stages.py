@@ -1,0 +1,143 @@
+"""Parity of every single-frame operator of libvo_hip.so against the CPU oracle.
+
+All stages here are integer work: the bar is bit-exact equality."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gray_bgr_and_bgra(ctx, oracle, vga_seq):
+    bgr = vga_seq["frames"][0]
+    assert np.array_equal(ctx.gray(bgr), oracle.gray(bgr))
+    bgra = np.concatenate([bgr, np.full(bgr.shape[:2] + (1,), 255, np.uint8)], axis=2)
+    assert np.array_equal(ctx.gray(bgra), oracle.gray(bgra))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (376, 1241), (97, 131), (16, 16)])
+def test_gray_ragged_sizes(ctx, oracle, shape):
+    rng = np.random.default_rng(5)
+    for cn in (3, 4):
+        img = rng.integers(0, 256, shape + (cn,), dtype=np.uint8)
+        assert np.array_equal(ctx.gray(img), oracle.gray(img))
+
+
+@pytest.mark.parametrize("thr", [0, 5, 20, 60, 255])
+def test_fast_score_map(ctx, oracle, vga_seq, thr):
+    g = oracle.gray(vga_seq["frames"][0])
+    assert np.array_equal(ctx.fast_score(g, thr), oracle.fast_score_map(g, thr))
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (97, 131), (16, 16), (7, 7), (33, 300)])
+def test_fast_score_random_and_ragged(ctx, oracle, shape):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(ctx.fast_score(g, 10), oracle.fast_score_map(g, 10))
+    # low-contrast blocks give plateaus and ties
+    g2 = (np.kron(rng.integers(0, 4, (shape[0] // 4 + 1, shape[1] // 4 + 1)), np.ones((4, 4))) * 60).astype(np.uint8)
+    g2 = np.ascontiguousarray(g2[:shape[0], :shape[1]])
+    assert np.array_equal(ctx.fast_score(g2, 20), oracle.fast_score_map(g2, 20))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (376, 1241), (97, 131), (16, 16), (7, 9)])
+def test_blur7(ctx, oracle, shape):
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(ctx.blur7(g), oracle.blur7(g))
+    sat = np.full(shape, 255, np.uint8)
+    assert np.array_equal(ctx.blur7(sat), oracle.blur7(sat))
+
+
+@pytest.mark.parametrize("nfeat", [1000, 300, 4000])
+def test_detect_matches_oracle(ctx, oracle, vga_seq, nfeat):
+    g = oracle.gray(vga_seq["frames"][0])
+    k_ref, d_ref = oracle.detect(g, nfeat, 20)
+    k, d = ctx.detect(g, nfeat, 20)
+    assert len(k) == len(k_ref) > 0
+    assert np.array_equal(k, k_ref)
+    assert np.array_equal(d, d_ref)
+
+
+def test_detect_heavy_ties(ctx, oracle):
+    # blocky image: thousands of corners share a handful of scores, so the
+    # top-N cut falls inside a tie class and the raster tie-break decides
+    rng = np.random.default_rng(3)
+    g = (np.kron(rng.integers(0, 2, (60, 80)), np.ones((8, 8))) * 200 + 20).astype(np.uint8)
+    k_ref, d_ref = oracle.detect(g, 500, 20)
+    k, d = ctx.detect(g, 500, 20)
+    assert np.array_equal(k, k_ref) and np.array_equal(d, d_ref)
+
+
+def test_detect_empty_and_tiny(ctx, oracle):
+    flat = np.full((120, 160), 77, np.uint8)
+    k, d = ctx.detect(flat, 100, 20)
+    assert len(k) == 0 and d.shape == (0, 32)
+    rng = np.random.default_rng(1)
+    small = rng.integers(0, 256, (40, 50), dtype=np.uint8)  # narrower than 2*31: border filter drops all
+    k_ref, _ = oracle.detect(small, 100, 20)
+    k, _ = ctx.detect(small, 100, 20)
+    assert len(k) == len(k_ref) == 0
+
+
+def test_knn2(ctx, oracle, vga_seq):
+    g0, g1 = (oracle.gray(f) for f in vga_seq["frames"][:2])
+    _, d0 = oracle.detect(g0, 1000, 20)
+    _, d1 = oracle.detect(g1, 1000, 20)
+    assert np.array_equal(ctx.knn2(d0, d1), oracle.knn2(d0, d1))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 1), (3, 2), (129, 513), (700, 3999), (4000, 4000)])
+def test_knn2_random_sizes_and_ties(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 31 + nt)
+    # few distinct descriptors -> many exact distance ties; lowest index must win
+    pool = rng.integers(0, 256, (17, 32), dtype=np.uint8)
+    q = pool[rng.integers(0, 17, nq)]
+    t = pool[rng.integers(0, 17, nt)]
+    assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+
+
+def _pair_points(oracle, seq, nfeat=1000):
+    g0, g1 = (oracle.gray(f) for f in seq["frames"][:2])
+    k0, d0 = oracle.detect(g0, nfeat, 20)
+    k1, d1 = oracle.detect(g1, nfeat, 20)
+    knn = oracle.knn2(d0, d1)
+    good = oracle.ratio_test(knn, len(k1), 0.7, k0, k1)
+    return k0, d0, k1, d1, good
+
+
+def test_fundamental_ransac_mask(ctx, oracle, vga_seq):
+    k0, d0, k1, d1, good = _pair_points(oracle, vga_seq)
+    p1 = np.stack([good["px"], good["py"]], 1)
+    p2 = np.stack([good["cx"], good["cy"]], 1)
+    ok_r, F_r, mask_r, it_r = oracle.find_fundamental_ransac(p1, p2)
+    ok, F, mask, it = ctx.find_fundamental_ransac(p1, p2)
+    assert ok == ok_r and it == it_r
+    assert np.array_equal(mask, mask_r)
+    np.testing.assert_allclose(F, F_r, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("outlier_frac,n", [(0.4, 600), (0.6, 300), (0.0, 50), (0.8, 2000)])
+def test_fundamental_ransac_with_outliers(ctx, oracle, vga_seq, outlier_frac, n):
+    k0, d0, k1, d1, good = _pair_points(oracle, vga_seq)
+    rng = np.random.default_rng(int(outlier_frac * 100) + n)
+    sel = rng.integers(0, len(good), n)
+    p1 = np.stack([good["px"], good["py"]], 1)[sel].astype(np.float32)
+    p2 = np.stack([good["cx"], good["cy"]], 1)[sel].astype(np.float32)
+    bad = rng.random(n) < outlier_frac
+    p2[bad] = rng.uniform([0, 0], [640, 480], (int(bad.sum()), 2)).astype(np.float32)
+    ok_r, F_r, mask_r, it_r = oracle.find_fundamental_ransac(p1, p2)
+    ok, F, mask, it = ctx.find_fundamental_ransac(p1, p2)
+    assert (ok, it) == (ok_r, it_r)
+    assert np.array_equal(mask, mask_r)
+
+
+def test_match_features_end_to_end(ctx, oracle, vga_seq):
+    k0, d0, k1, d1, _ = _pair_points(oracle, vga_seq)
+    knn = oracle.knn2(d0, d1)
+    m_ref, _, _ = oracle.match_filter(knn, len(k1), k0, k1, 0.7)
+    m = ctx.match(k0, d0, k1, d1, 0.7)
+    assert len(m) == len(m_ref) > 50
+    assert np.array_equal(m, m_ref)

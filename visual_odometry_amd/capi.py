@@ -1,0 +1,174 @@
+"""ctypes binding of libvo_hip.so (the C ABI declared in include/vo_hip.h).
+
+The library is the product; this module only marshals numpy arrays to plain
+pointers.  There is no fallback: a missing library or GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+
+VO_OK = 0
+VO_ERR_ARG = -1
+VO_ERR_HIP = -2
+VO_ERR_STATE = -3
+VO_ERR_UNSUPPORTED = -4
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+KNN_DTYPE = np.dtype([("idx0", "<i4"), ("dist0", "<i4"), ("idx1", "<i4"), ("dist1", "<i4")])
+MATCH_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("distance", "<f4"),
+                        ("px", "<f4"), ("py", "<f4"), ("cx", "<f4"), ("cy", "<f4")])
+
+
+class VoCfg(C.Structure):
+    _fields_ = [("max_width", C.c_int), ("max_height", C.c_int), ("max_features", C.c_int),
+                ("max_batch", C.c_int), ("gray_b", C.c_int), ("gray_g", C.c_int),
+                ("gray_r", C.c_int), ("gray_shift", C.c_int)]
+
+
+class VoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvo_hip error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/vo_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+EXPORTS = {
+    "vo_create": (_P, [C.c_int, C.POINTER(VoCfg)]),
+    "vo_destroy": (None, [_P]),
+    "vo_last_error": (C.c_char_p, [_P]),
+    "vo_abi_version": (C.c_int, []),
+    "vo_gray": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "vo_fast_score": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "vo_blur7": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "vo_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "vo_knn2_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
+    "vo_find_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
+                                             _P, _P, _P, _P]),
+    "vo_match_features": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvo_hip.so and bind every exported symbol. Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                              "(make -C visual_odometry_amd/csrc)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One vo_ctx: a camera stream's device state on one GPU."""
+
+    def __init__(self, device=0, max_width=1280, max_height=720, max_features=2000, max_batch=1):
+        self._lib = load()
+        cfg = VoCfg(max_width, max_height, max_features, max_batch, 0, 0, 0, 0)
+        self._h = self._lib.vo_create(device, C.byref(cfg))
+        if not self._h:
+            raise VoError(VO_ERR_HIP, self._lib.vo_last_error(None).decode())
+        self.max_features = max_features
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != VO_OK:
+            raise VoError(rc, self._lib.vo_last_error(self._h).decode())
+
+    # ---- single-frame operators -------------------------------------
+    def gray(self, img: np.ndarray) -> np.ndarray:
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w, cn = img.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self._lib.vo_gray(self._h, _ptr(img), w, h, w * cn, cn, _ptr(out), w))
+        return out
+
+    def fast_score(self, gray: np.ndarray, threshold: int) -> np.ndarray:
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self._lib.vo_fast_score(self._h, _ptr(gray), w, h, w, threshold, _ptr(out), w))
+        return out
+
+    def blur7(self, gray: np.ndarray) -> np.ndarray:
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        out = np.empty((h, w), np.uint8)
+        self._check(self._lib.vo_blur7(self._h, _ptr(gray), w, h, w, _ptr(out), w))
+        return out
+
+    def detect(self, gray: np.ndarray, max_features: int = 1000, fast_threshold: int = 20):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        kps = np.zeros(max_features, KP_DTYPE)
+        desc = np.zeros((max_features, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self._lib.vo_detect(self._h, _ptr(gray), w, h, w, max_features, fast_threshold,
+                                        _ptr(kps), _ptr(desc), C.addressof(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def knn2(self, query: np.ndarray, train: np.ndarray) -> np.ndarray:
+        query = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+        train = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(query), KNN_DTYPE)
+        self._check(self._lib.vo_knn2_hamming(self._h, _ptr(query), len(query), _ptr(train),
+                                              len(train), _ptr(out)))
+        return out
+
+    def find_fundamental_ransac(self, p1, p2, threshold=3.0, confidence=0.99, max_iters=1000):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        mask = np.zeros(max(n, 1), np.uint8)
+        F = np.zeros(9, np.float64)
+        found = C.c_int(0)
+        iters = C.c_int(0)
+        self._check(self._lib.vo_find_fundamental_ransac(
+            self._h, _ptr(p1), _ptr(p2), n, threshold, confidence, max_iters, _ptr(mask), _ptr(F),
+            C.addressof(found), C.addressof(iters)))
+        return bool(found.value), F.reshape(3, 3), mask[:n].copy(), iters.value
+
+    def match(self, prev_kps, prev_desc, curr_kps, curr_desc, ratio=0.7) -> np.ndarray:
+        prev_kps = np.ascontiguousarray(prev_kps, KP_DTYPE)
+        curr_kps = np.ascontiguousarray(curr_kps, KP_DTYPE)
+        prev_desc = np.ascontiguousarray(prev_desc, np.uint8)
+        curr_desc = np.ascontiguousarray(curr_desc, np.uint8)
+        out = np.zeros(max(len(prev_kps), 1), MATCH_DTYPE)
+        n = C.c_int(0)
+        self._check(self._lib.vo_match_features(self._h, _ptr(prev_kps), _ptr(prev_desc), len(prev_kps),
+                                                _ptr(curr_kps), _ptr(curr_desc), len(curr_kps), ratio,
+                                                _ptr(out), C.addressof(n)))
+        return out[:n.value].copy()

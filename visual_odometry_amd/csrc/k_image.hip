@@ -1,0 +1,548 @@
+// Image-side kernels of the detector for gfx950: BGR->gray, the fused
+// FAST-9/16 score + 7x7 Gaussian tile kernel, non-max suppression with
+// wave-ballot compaction, top-N selection and rBRIEF-256.
+//
+// All arithmetic here is 8/16/32-bit integer and bit-exact by construction;
+// the work is HBM/LDS/VALU integer work, there is nothing MFMA-shaped.
+#include "vo_internal.h"
+
+namespace vo {
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    // BORDER_REFLECT_101: ... 2 1 | 0 1 2 ... n-1 | n-2 n-3 ...
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r, GrayCoeffs c)
+{
+    return (b * c.b + g * c.g + r * c.r + (1u << (c.shift - 1))) >> c.shift;
+}
+
+// byte k (0..11) of the 96-bit little-endian window {d0, d1, d2}
+template <int K>
+__device__ __forceinline__ uint32_t win_byte(uint32_t d0, uint32_t d1, uint32_t d2)
+{
+    static_assert(K >= 0 && K < 12, "window is 12 bytes");
+    uint32_t d = K < 4 ? d0 : (K < 8 ? d1 : d2);
+    return __builtin_amdgcn_ubfe(d, 8 * (K & 3), 8);
+}
+
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+
+// --------------------------------------------------------------------- gray
+
+// One thread converts four horizontally adjacent pixels and stores one dword.
+// reference src/frame_processor.cpp:204-208 (cv::cvtColor BGR2GRAY)
+template <int CN>
+__global__ __launch_bounds__(256) void k_gray(const uint8_t *__restrict__ src, int width, int height,
+                                              int src_stride, size_t src_frame_stride, PlaneBatch dst,
+                                              GrayCoeffs c)
+{
+    const int gx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = gx * 4;
+    if (y >= height || x >= width) return;
+    const uint8_t *row = src + blockIdx.z * src_frame_stride + (size_t)y * src_stride;
+    uint8_t *drow = dst.base + blockIdx.z * dst.plane_stride + (size_t)y * dst.pitch;
+    uint32_t out = 0;
+    if (CN == 4 && ((((uintptr_t)row) & 15) == 0) && x + 3 < width) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + (size_t)x * 4);
+        const uint32_t p[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out |= gray_of(p[i] & 255u, (p[i] >> 8) & 255u, (p[i] >> 16) & 255u, c) << (8 * i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (x + i < width) {
+                const uint8_t *p = row + (size_t)(x + i) * CN;
+                out |= gray_of(p[0], p[1], p[2], c) << (8 * i);
+            }
+        }
+    }
+    *reinterpret_cast<uint32_t *>(drow + x) = out;  // pitch is padded: always in bounds
+}
+
+void launch_gray(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
+                 int channels, PlaneBatch dst, int batch, GrayCoeffs c, hipStream_t s)
+{
+    dim3 grid((width + 255) / 256, (height + 3) / 4, batch);
+    if (channels == 4)
+        hipLaunchKernelGGL(k_gray<4>, grid, dim3(256), 0, s, src, width, height, src_stride,
+                           src_frame_stride, dst, c);
+    else
+        hipLaunchKernelGGL(k_gray<3>, grid, dim3(256), 0, s, src, width, height, src_stride,
+                           src_frame_stride, dst, c);
+}
+
+// ------------------------------------------------ fused FAST score + blur
+
+constexpr int FE_TW = 128;             // interior tile width
+constexpr int FE_TH = 16;              // interior tile height
+constexpr int FE_HALO = 3;             // FAST ring radius == blur radius
+constexpr int FE_GPITCH = FE_TW + 16;  // LDS gray row: image x0-4 .. x0+TW+11, 16-B aligned
+constexpr int FE_GROWS = FE_TH + 2 * FE_HALO;
+constexpr int FE_THREADS = 512;
+
+// FAST-9/16 score of one pixel from its 16 ring values p[] and centre v:
+//   A = max over the 16 arcs of 9 of min(v - p) = v - min_arcs(max_arc p)
+//   B = max over arcs of min(p - v)           = max_arcs(min_arc p) - v
+//   score = max(A, B) - 1 when that is >= threshold (the pixel is then a
+//   corner for every t <= score), else 0.
+// Same value as cv::FAST's cornerScore<16> (reference src/feature_detector.cpp:59).
+__device__ __forceinline__ uint32_t fast_score(const uint32_t (&p)[16], uint32_t v, int thr)
+{
+    uint32_t mx3[16], mn3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mx3[k] = umax3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        mn3[k] = umin3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    }
+    uint32_t lo = 255u, hi = 0u;  // min over arcs of max; max over arcs of min
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo = min(lo, umax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+        hi = max(hi, umin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+    }
+    const int a = (int)v - (int)lo, b = (int)hi - (int)v;
+    const int sc = max(a, b) - 1;
+    return sc >= thr ? (uint32_t)sc : 0u;
+}
+
+// ring value k (OpenCV order, dx/dy below) for pixel i of a 4-pixel group,
+// taken from the seven row windows w[row][3]; tile column of pixel i is 4+i.
+//   k : 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15
+//   dx: 0 1 2 3 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1
+//   dy: 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1 0 1 2 3
+#define FE_RING(I, K, DX, DY) p[K] = win_byte<4 + I + (DX)>(w[3 + (DY)][0], w[3 + (DY)][1], w[3 + (DY)][2])
+
+template <int I>
+__device__ __forceinline__ uint32_t fast_pixel(const uint32_t (&w)[7][3], int thr)
+{
+    uint32_t p[16];
+    FE_RING(I, 0, 0, 3);   FE_RING(I, 1, 1, 3);   FE_RING(I, 2, 2, 2);    FE_RING(I, 3, 3, 1);
+    FE_RING(I, 4, 3, 0);   FE_RING(I, 5, 3, -1);  FE_RING(I, 6, 2, -2);   FE_RING(I, 7, 1, -3);
+    FE_RING(I, 8, 0, -3);  FE_RING(I, 9, -1, -3); FE_RING(I, 10, -2, -2); FE_RING(I, 11, -3, -1);
+    FE_RING(I, 12, -3, 0); FE_RING(I, 13, -3, 1); FE_RING(I, 14, -2, 2);  FE_RING(I, 15, -1, 3);
+    const uint32_t v = win_byte<4 + I>(w[3][0], w[3][1], w[3][2]);
+    return fast_score(p, v, thr);
+}
+
+// 7-tap row sum of pixel i (tile column 4+i) from one row window
+template <int I>
+__device__ __forceinline__ uint32_t hsum7(uint32_t d0, uint32_t d1, uint32_t d2)
+{
+    return 18u * (win_byte<1 + I>(d0, d1, d2) + win_byte<7 + I>(d0, d1, d2)) +
+           34u * (win_byte<2 + I>(d0, d1, d2) + win_byte<6 + I>(d0, d1, d2)) +
+           49u * (win_byte<3 + I>(d0, d1, d2) + win_byte<5 + I>(d0, d1, d2)) +
+           55u * win_byte<4 + I>(d0, d1, d2);
+}
+
+// One block = one 128x16 tile of one frame.  Stage the tile plus a 3-px halo
+// in LDS as 8-bit gray (converting from BGR/BGRA on the way when CN > 1),
+// then every thread owns four adjacent pixels: FAST score from seven 12-byte
+// row windows, Gaussian through an LDS buffer of 16-bit row sums.
+template <int CN>
+__global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
+                                                         int height, int src_stride,
+                                                         size_t src_frame_stride, PlaneBatch gray_out,
+                                                         PlaneBatch score, PlaneBatch blur, int thr,
+                                                         GrayCoeffs c)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_GPITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hsum[FE_GROWS * FE_TW];
+
+    const int x0 = blockIdx.x * FE_TW, y0 = blockIdx.y * FE_TH;
+    const int f = blockIdx.z;
+    const uint8_t *img = src + f * src_frame_stride;
+
+    // stage: tile column tc <-> image x0 - 4 + tc, tile row tr <-> image y0 - 3 + tr
+    for (int i = threadIdx.x; i < FE_GROWS * (FE_GPITCH / 4); i += FE_THREADS) {
+        const int tr = i / (FE_GPITCH / 4), tq = i % (FE_GPITCH / 4);
+        const int yy = reflect101(y0 - FE_HALO + tr, height);
+        const uint8_t *row = img + (size_t)yy * src_stride;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int xx = reflect101(x0 - 4 + tq * 4 + j, width);
+            uint32_t g;
+            if (CN == 1) {
+                g = row[xx];
+            } else if (CN == 4) {
+                const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
+                g = gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c);
+            } else {
+                const uint8_t *p = row + (size_t)xx * 3;
+                g = gray_of(p[0], p[1], p[2], c);
+            }
+            packed |= g << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_GPITCH + tq * 4]) = packed;
+    }
+    __syncthreads();
+
+    const int gx = threadIdx.x & 31, gy = threadIdx.x >> 5;  // 32 groups x 16 rows
+    const int x = x0 + gx * 4, y = y0 + gy;
+
+    // horizontal pass of the Gaussian for all 22 staged rows
+    if (blur.base) {
+        for (int t = threadIdx.x; t < FE_GROWS * 32; t += FE_THREADS) {
+            const int tr = t >> 5, tg = t & 31;
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[tr * FE_GPITCH + tg * 4]);
+            const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
+            uint2 o;
+            o.x = hsum7<0>(d0, d1, d2) | (hsum7<1>(d0, d1, d2) << 16);
+            o.y = hsum7<2>(d0, d1, d2) | (hsum7<3>(d0, d1, d2) << 16);
+            *reinterpret_cast<uint2 *>(&s_hsum[tr * FE_TW + tg * 4]) = o;
+        }
+    }
+
+    // seven row windows around this thread's four pixels
+    uint32_t w[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[(gy + r) * FE_GPITCH + gx * 4]);
+        w[r][0] = rw[0]; w[r][1] = rw[1]; w[r][2] = rw[2];
+    }
+
+    if (gray_out.base && y < height) {
+        // centre row window holds tile columns 4gx .. 4gx+11; pixels are bytes 4..7
+        *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
+            w[3][1];
+    }
+
+    if (score.base) {
+        uint32_t s4 = 0;
+        const bool row_ok = y >= 3 && y < height - 3;
+        if (row_ok) {
+            const uint32_t s0 = fast_pixel<0>(w, thr), s1 = fast_pixel<1>(w, thr);
+            const uint32_t s2 = fast_pixel<2>(w, thr), s3 = fast_pixel<3>(w, thr);
+            s4 = (x + 0 >= 3 && x + 0 < width - 3 ? s0 : 0u) | ((x + 1 >= 3 && x + 1 < width - 3 ? s1 : 0u) << 8) |
+                 ((x + 2 >= 3 && x + 2 < width - 3 ? s2 : 0u) << 16) |
+                 ((x + 3 >= 3 && x + 3 < width - 3 ? s3 : 0u) << 24);
+        }
+        // planes are padded to whole tiles, so this store is always in bounds
+        *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) = s4;
+    }
+
+    if (blur.base) {
+        __syncthreads();
+        uint32_t acc[4] = {0, 0, 0, 0};
+        const uint32_t kq[7] = {18, 34, 49, 55, 49, 34, 18};
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const uint2 h = *reinterpret_cast<const uint2 *>(&s_hsum[(gy + r) * FE_TW + gx * 4]);
+            acc[0] += kq[r] * (h.x & 0xffffu);
+            acc[1] += kq[r] * (h.x >> 16);
+            acc[2] += kq[r] * (h.y & 0xffffu);
+            acc[3] += kq[r] * (h.y >> 16);
+        }
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) o |= min((acc[i] + (1u << 15)) >> 16, 255u) << (8 * i);
+        if (y < height)
+            *reinterpret_cast<uint32_t *>(blur.base + f * blur.plane_stride + (size_t)y * blur.pitch + x) = o;
+    }
+}
+
+void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
+                     int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
+                     int batch, GrayCoeffs c, hipStream_t s)
+{
+    dim3 grid((width + FE_TW - 1) / FE_TW, (height + FE_TH - 1) / FE_TH, batch);
+    threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
+    if (channels == 1)
+        hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
+                           src_frame_stride, gray_out, score, blur, threshold, c);
+    else if (channels == 3)
+        hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
+                           src_frame_stride, gray_out, score, blur, threshold, c);
+    else
+        hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
+                           src_frame_stride, gray_out, score, blur, threshold, c);
+}
+
+// ------------------------------------------------------------ NMS + emit
+
+// Thread = four adjacent score bytes.  A corner survives when its score is
+// strictly greater than all eight neighbours (cv::FAST with
+// nonmaxSuppression=true, reference src/feature_detector.cpp:59).  Survivors
+// are compacted per wave with ballots and appended with one atomic per wave.
+__global__ __launch_bounds__(256) void k_nms_emit(PlaneBatch score, int width, int height,
+                                                  uint32_t *__restrict__ cand,
+                                                  uint32_t *__restrict__ cand_count, int cand_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int gx = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = gx * 4;
+    const int f = blockIdx.z;
+    const uint8_t *plane = score.base + f * score.plane_stride;
+    const int pitch = score.pitch;
+
+    uint32_t flags = 0;  // bit i: pixel x+i survives
+    uint32_t mid = 0;
+    const bool in = (y >= 3 && y < height - 3 && x < width);
+    if (in) mid = *reinterpret_cast<const uint32_t *>(plane + (size_t)y * pitch + x);
+    if (mid) {
+        // 3 rows x 6 bytes (x-1 .. x+4) as 64-bit windows
+        uint64_t rw[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint8_t *row = plane + (size_t)(y - 1 + r) * pitch;
+            const uint32_t m = *reinterpret_cast<const uint32_t *>(row + x);
+            const uint32_t l = x > 0 ? row[x - 1] : 0u;
+            const uint32_t rr = x + 4 < pitch ? row[x + 4] : 0u;
+            rw[r] = (uint64_t)l | ((uint64_t)m << 8) | ((uint64_t)rr << 40);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t sc = (uint32_t)(rw[1] >> (8 * (i + 1))) & 255u;
+            if (!sc) continue;
+            bool keep = true;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    if (r == 1 && d == 1) continue;
+                    keep = keep && sc > ((uint32_t)(rw[r] >> (8 * (i + d))) & 255u);
+                }
+            }
+            if (keep) flags |= 1u << i;
+        }
+    }
+
+    // wave compaction: one atomic per wave
+    uint64_t m[4];
+    int total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        m[i] = __ballot((flags >> i) & 1u);
+        total += __popcll(m[i]);
+    }
+    if (total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[f], (uint32_t)total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t off = base;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if ((flags >> i) & 1u) {
+            const uint32_t slot = off + __popcll(m[i] & lt);
+            const uint32_t sc = (mid >> (8 * i)) & 255u;
+            if (slot < (uint32_t)cand_cap)
+                cand[(size_t)f * cand_cap + slot] = ((255u - sc) << 24) | (uint32_t)(y * width + x + i);
+        }
+        off += __popcll(m[i]);
+    }
+}
+
+void launch_nms_emit(PlaneBatch score, int width, int height, uint32_t *cand, uint32_t *cand_count,
+                     int cand_cap, int batch, hipStream_t s)
+{
+    dim3 grid((width + 255) / 256, (height + 3) / 4, batch);
+    hipLaunchKernelGGL(k_nms_emit, grid, dim3(256), 0, s, score, width, height, cand, cand_count, cand_cap);
+}
+
+// ---------------------------------------------------------------- select
+
+constexpr int SEL_THREADS = 1024;
+
+__device__ __forceinline__ void bitonic_sort_lds(uint32_t *keys, int n_pow2)
+{
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < n_pow2 / 2; t += SEL_THREADS) {
+                // t-th compare-exchange of this stage
+                const int i = ((t / j) * 2 * j) + (t % j);
+                const int p = i + j;
+                const bool up = ((i & k) == 0);
+                const uint32_t a = keys[i], b = keys[p];
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One block per frame.  reference src/feature_detector.cpp:62-68 sorts all
+// corners by response and keeps max_features; here the same set (with the
+// canonical tie order: response descending, raster index ascending) is found
+// with a two-level histogram select (score, then image row inside the tied
+// score class) so that at most max_features + width/2 keys are sorted in LDS.
+// Then KeyPointsFilter::runByImageBorder(31) as done inside ORB::compute
+// (reference src/feature_detector.cpp:73), order preserved.
+__global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restrict__ cand,
+                                                        const uint32_t *__restrict__ cand_count, int cand_cap,
+                                                        int width, int height, int max_features, int border,
+                                                        vo_kp *__restrict__ kps, int kp_stride,
+                                                        int *__restrict__ nkp)
+{
+    __shared__ uint32_t s_keys[kSelectCap];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_rows[kMaxDim];
+    __shared__ uint32_t s_scan[SEL_THREADS];
+    __shared__ int s_cut_bin, s_need, s_cut_row, s_count;
+
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t *c = cand + (size_t)f * cand_cap;
+    const int M = min((int)cand_count[f], cand_cap);
+    const bool all = M <= max_features;
+
+    if (tid == 0) { s_count = 0; s_cut_bin = 256; s_need = 0; s_cut_row = kMaxDim; }
+    if (!all) {
+        for (int i = tid; i < 256; i += SEL_THREADS) s_hist[i] = 0;
+        for (int i = tid; i < kMaxDim; i += SEL_THREADS) s_rows[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < M; i += SEL_THREADS) atomicAdd(&s_hist[c[i] >> 24], 1u);
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, b = 0;
+            for (; b < 256; b++) {
+                if (cum + (int)s_hist[b] >= max_features) break;
+                cum += (int)s_hist[b];
+            }
+            s_cut_bin = b;
+            s_need = max_features - cum;  // >= 1 keys to take from the tied class
+        }
+        __syncthreads();
+        const uint32_t cb = (uint32_t)s_cut_bin;
+        for (int i = tid; i < M; i += SEL_THREADS) {
+            const uint32_t k = c[i];
+            if ((k >> 24) == cb) atomicAdd(&s_rows[(k & 0xffffffu) / (uint32_t)width], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, r = 0;
+            for (; r < height; r++) {
+                cum += (int)s_rows[r];
+                if (cum >= s_need) break;
+            }
+            s_cut_row = r;
+        }
+    }
+    __syncthreads();
+
+    // gather the keys to sort
+    {
+        const uint32_t cb = (uint32_t)s_cut_bin, cr = (uint32_t)s_cut_row;
+        for (int i = tid; i < M; i += SEL_THREADS) {
+            const uint32_t k = c[i];
+            bool take;
+            uint32_t key;
+            if (all) {
+                take = true;
+                key = ((k & 0xffffffu) << 8) | (k >> 24);  // raster order
+            } else {
+                const uint32_t b = k >> 24;
+                take = b < cb || (b == cb && (k & 0xffffffu) / (uint32_t)width <= cr);
+                key = k;
+            }
+            if (take) {
+                const int slot = atomicAdd(&s_count, 1);
+                if (slot < kSelectCap) s_keys[slot] = key;
+            }
+        }
+    }
+    __syncthreads();
+    const int K = min(s_count, kSelectCap);
+    int n_pow2 = 1;
+    while (n_pow2 < K) n_pow2 <<= 1;
+    for (int i = K + tid; i < n_pow2; i += SEL_THREADS) s_keys[i] = 0xffffffffu;
+    __syncthreads();
+    if (n_pow2 > 1) bitonic_sort_lds(s_keys, n_pow2);
+
+    // border filter + ordered compaction
+    const int n_sel = min(K, max_features);
+    const int per = (n_sel + SEL_THREADS - 1) / SEL_THREADS;  // consecutive keys per thread
+    const int begin = tid * per, end = min(begin + per, n_sel);
+    const bool size_ok = width > 2 * border && height > 2 * border;
+    int cnt = 0;
+    for (int i = begin; i < end; i++) {
+        const uint32_t key = s_keys[i];
+        const uint32_t raster = all ? key >> 8 : key & 0xffffffu;
+        const int yy = raster / (uint32_t)width, xx = raster - yy * width;
+        cnt += (size_ok && xx >= border && xx < width - border && yy >= border && yy < height - border);
+    }
+    s_scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < SEL_THREADS; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int out = (int)s_scan[tid] - cnt;
+    vo_kp *o = kps + (size_t)f * kp_stride;
+    for (int i = begin; i < end; i++) {
+        const uint32_t key = s_keys[i];
+        const uint32_t raster = all ? key >> 8 : key & 0xffffffu;
+        const uint32_t sc = 255u - (all ? key & 255u : key >> 24);
+        const int yy = raster / (uint32_t)width, xx = raster - yy * width;
+        if (size_ok && xx >= border && xx < width - border && yy >= border && yy < height - border) {
+            vo_kp kp;
+            kp.x = (float)xx; kp.y = (float)yy; kp.size = 7.f; kp.angle = -1.f;
+            kp.response = (float)sc; kp.octave = 0;
+            o[out++] = kp;
+        }
+    }
+    if (tid == SEL_THREADS - 1) nkp[f] = (int)s_scan[tid];
+}
+
+void launch_select(const uint32_t *cand, const uint32_t *cand_count, int cand_cap, int width, int height,
+                   int max_features, int border, vo_kp *kps, int kp_stride, int *nkp, int batch,
+                   hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_THREADS), 0, s, cand, cand_count, cand_cap, width,
+                       height, max_features, border, kps, kp_stride, nkp);
+}
+
+// ----------------------------------------------------------------- BRIEF
+
+// 32 lanes per keypoint, one descriptor byte (8 tests) per lane.
+// cv::ORB::compute's computeOrbDescriptors with WTA_K = 2
+// (reference src/feature_detector.cpp:73).  The pattern holds the 512 sample
+// offsets already rotated by the (constant) keypoint angle and rounded.
+__global__ __launch_bounds__(256) void k_brief(PlaneBatch blur, const vo_kp *__restrict__ kps, int kp_stride,
+                                               const int *__restrict__ nkp,
+                                               const int8_t *__restrict__ pattern,
+                                               uint8_t *__restrict__ desc)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
+    reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int byte = threadIdx.x & 31;
+    if (k >= nkp[f]) return;
+    const vo_kp kp = kps[(size_t)f * kp_stride + k];
+    const int pitch = blur.pitch;
+    const uint8_t *center = blur.base + f * blur.plane_stride + (size_t)__float2int_rn(kp.y) * pitch +
+                            __float2int_rn(kp.x);
+    const int8_t *p = s_pat + byte * 32;
+    uint32_t val = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const int t0 = center[p[4 * b + 1] * pitch + p[4 * b + 0]];
+        const int t1 = center[p[4 * b + 3] * pitch + p[4 * b + 2]];
+        val |= (uint32_t)(t0 < t1) << b;
+    }
+    desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
+}
+
+void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride, const int *nkp, const int8_t *pattern,
+                  uint8_t *desc, int batch, hipStream_t s)
+{
+    dim3 grid((kp_stride + 7) / 8, batch);
+    hipLaunchKernelGGL(k_brief, grid, dim3(256), 0, s, blur, kps, kp_stride, nkp, pattern, desc);
+}
+
+}  // namespace vo

@@ -1,0 +1,181 @@
+// Matching kernels for gfx950: brute-force Hamming kNN-2 over LDS-staged
+// descriptor tiles (XOR + v_bcnt_u32_b32), merge + Lowe ratio test with
+// ordered compaction.  Integer work only; results are bit-exact.
+#include "vo_internal.h"
+
+namespace vo {
+
+constexpr int KNN_THREADS = 256;
+constexpr int KNN_QPL = 2;                           // queries per lane
+constexpr int KNN_QPB = KNN_THREADS * KNN_QPL;       // queries per block
+constexpr int KNN_TILE = 128;                        // train descriptors per LDS tile
+
+// Per query the two smallest keys are tracked, k0 <= k1, with
+// key = (distance << 16) | train index: the order is (distance, then lower
+// train index), the order in which cv::BFMatcher::knnMatch reports equal
+// distances (reference src/feature_matcher.cpp:27-31).
+__global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
+                                                      const int *__restrict__ nkp,
+                                                      const int *__restrict__ q_slot,
+                                                      const int *__restrict__ t_slot, int kp_stride,
+                                                      uint2 *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tile[KNN_TILE * 2];
+
+    const int pair = blockIdx.z, split = blockIdx.y;
+    const int qs = q_slot[pair], ts = t_slot[pair];
+    const int nq = nkp[qs], nt = nkp[ts];
+    const int qbase = blockIdx.x * KNN_QPB;
+    if (qbase >= nq) return;
+
+    const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
+    const uint4 *td = reinterpret_cast<const uint4 *>(desc + ts * slot_stride);
+
+    uint4 qa[KNN_QPL], qb[KNN_QPL];
+    uint32_t k0[KNN_QPL], k1[KNN_QPL];
+#pragma unroll
+    for (int i = 0; i < KNN_QPL; i++) {
+        const int q = min(qbase + i * KNN_THREADS + (int)threadIdx.x, nq - 1);
+        qa[i] = qd[2 * q];
+        qb[i] = qd[2 * q + 1];
+        k0[i] = k1[i] = 0xffffffffu;
+    }
+
+    // this block's share of the train set, in whole tiles
+    const int tiles = (nt + KNN_TILE - 1) / KNN_TILE;
+    const int per = (tiles + kKnnSplits - 1) / kKnnSplits;
+    const int tile_lo = split * per, tile_hi = min(tile_lo + per, tiles);
+
+    for (int tile = tile_lo; tile < tile_hi; tile++) {
+        const int j0 = tile * KNN_TILE;
+        const int jn = min(KNN_TILE, nt - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < jn * 2) s_tile[threadIdx.x] = td[2 * j0 + threadIdx.x];
+        __syncthreads();
+        for (int j = 0; j < jn; j++) {
+            const uint4 ta = s_tile[2 * j], tb = s_tile[2 * j + 1];  // wave-uniform: LDS broadcast
+            const uint32_t jj = (uint32_t)(j0 + j);
+#pragma unroll
+            for (int i = 0; i < KNN_QPL; i++) {
+                uint32_t d = __popc(qa[i].x ^ ta.x);
+                d += __popc(qa[i].y ^ ta.y);
+                d += __popc(qa[i].z ^ ta.z);
+                d += __popc(qa[i].w ^ ta.w);
+                d += __popc(qb[i].x ^ tb.x);
+                d += __popc(qb[i].y ^ tb.y);
+                d += __popc(qb[i].z ^ tb.z);
+                d += __popc(qb[i].w ^ tb.w);
+                const uint32_t key = (d << 16) | jj;
+                const uint32_t n0 = min(k0[i], key);
+                k1[i] = min(k1[i], max(k0[i], key));
+                k0[i] = n0;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < KNN_QPL; i++) {
+        const int q = qbase + i * KNN_THREADS + (int)threadIdx.x;
+        if (q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(k0[i], k1[i]);
+    }
+}
+
+void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp, const int *q_slot,
+                 const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, hipStream_t s)
+{
+    dim3 grid((max_n + KNN_QPB - 1) / KNN_QPB, kKnnSplits, pairs);
+    hipLaunchKernelGGL(k_knn2, grid, dim3(KNN_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot, t_slot,
+                       kp_stride, partial);
+}
+
+// ------------------------------------------------------------- finalize
+
+constexpr int FIN_THREADS = 1024;
+
+// One block per frame pair: merge the split partial top-2 lists, emit the
+// vo_knn2 record of every query, run the ratio test
+// (reference src/feature_matcher.cpp:34-49: float32 d0 < ratio * d1) and
+// append survivors in query order.
+__global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__restrict__ partial,
+                                                                const vo_kp *__restrict__ kps, int kp_stride,
+                                                                const int *__restrict__ nkp,
+                                                                const int *__restrict__ q_slot,
+                                                                const int *__restrict__ t_slot, float ratio,
+                                                                vo_knn2 *__restrict__ knn,
+                                                                vo_match *__restrict__ good,
+                                                                int *__restrict__ n_good)
+{
+    __shared__ int s_wave[FIN_THREADS / kWave];
+    __shared__ int s_base;
+    const int pair = blockIdx.x;
+    const int qs = q_slot[pair], ts = t_slot[pair];
+    const int nq = nkp[qs], nt = nkp[ts];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const vo_kp *qk = kps + (size_t)qs * kp_stride;
+    const vo_kp *tk = kps + (size_t)ts * kp_stride;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+
+    for (int q0 = 0; q0 < nq; q0 += FIN_THREADS) {
+        const int q = q0 + tid;
+        bool keep = false;
+        vo_knn2 r = {-1, 0, -1, 0};
+        if (q < nq && nt > 0) {
+            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+#pragma unroll
+            for (int s = 0; s < kKnnSplits; s++) {
+                // splits that own no tile leave their slot unwritten: recompute ownership
+                const int tiles = (nt + KNN_TILE - 1) / KNN_TILE;
+                const int per = (tiles + kKnnSplits - 1) / kKnnSplits;
+                if (s * per >= tiles) continue;
+                const uint2 p = partial[((size_t)pair * kKnnSplits + s) * kp_stride + q];
+                uint32_t key = p.x;
+                uint32_t n0 = min(k0, key);
+                k1 = min(k1, max(k0, key));
+                k0 = n0;
+                key = p.y;
+                n0 = min(k0, key);
+                k1 = min(k1, max(k0, key));
+                k0 = n0;
+            }
+            if (k0 != 0xffffffffu) { r.idx0 = (int)(k0 & 0xffffu); r.dist0 = (int)(k0 >> 16); }
+            if (k1 != 0xffffffffu) { r.idx1 = (int)(k1 & 0xffffu); r.dist1 = (int)(k1 >> 16); }
+            if (knn) knn[(size_t)pair * kp_stride + q] = r;
+            keep = r.idx1 >= 0 && (float)r.dist0 < ratio * (float)r.dist1;
+        } else if (q < nq && knn) {
+            knn[(size_t)pair * kp_stride + q] = r;
+        }
+        // ordered compaction across the block
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (keep) {
+            const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+            vo_match o;
+            o.query = q; o.train = r.idx0; o.distance = (float)r.dist0;
+            o.px = qk[q].x; o.py = qk[q].y;
+            o.cx = tk[r.idx0].x; o.cy = tk[r.idx0].y;
+            good[(size_t)pair * kp_stride + slot] = o;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < FIN_THREADS / kWave; w++) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) n_good[pair] = s_base;
+}
+
+void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride, const int *nkp,
+                           const int *q_slot, const int *t_slot, float ratio, vo_knn2 *knn, vo_match *good,
+                           int *n_good, int pairs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_match_finalize, dim3(pairs), dim3(FIN_THREADS), 0, s, partial, kps, kp_stride, nkp,
+                       q_slot, t_slot, ratio, knn, good, n_good);
+}
+
+}  // namespace vo

@@ -1,0 +1,469 @@
+// Fundamental-matrix RANSAC (7-point) for gfx950, one workgroup per frame
+// pair, replaying cv::RNG's stream so that the hypothesis sequence and the
+// adaptive iteration count are those of
+//   cv::findFundamentalMat(prev, curr, FM_RANSAC, 3.0, 0.99, mask)
+// (reference src/feature_matcher.cpp:52-58), followed by the reference's
+// 100 px motion filter (reference src/feature_matcher.cpp:72-88).
+//
+// Hypotheses are generated and scored in rounds of FR_CHUNK iterations:
+//   1. all threads reduce a window of raw RNG words modulo n;
+//   2. every window offset is simulated as the start of one subset draw
+//      (7 distinct indices, redraw on duplicates, collinearity rejection);
+//   3. one lane chains the offsets into the iteration sequence;
+//   4. one lane per iteration solves the 7-point problem in fp64;
+//   5. all waves count inliers of every candidate matrix (fp64 error,
+//      float32 compare, as OpenCV does);
+//   6. one lane replays the sequential "best so far" logic and the adaptive
+//      iteration bound.
+// fp64 expressions are evaluated in a fixed order with contraction disabled.
+#include <float.h>
+#include <math.h>
+
+#include "vo_internal.h"
+
+namespace vo {
+
+constexpr int FR_THREADS = 512;
+constexpr int FR_CHUNK = 64;
+constexpr int FR_WIN = FR_CHUNK * 7 + 192;
+constexpr int FR_MAX_ATTEMPTS = 10000;
+
+struct FrShared {
+    double models[FR_CHUNK][3][9];
+    double best[9];
+    int nmodels[FR_CHUNK];
+    int counts[FR_CHUNK][3];
+    int start[FR_CHUNK];
+    uint16_t r[FR_WIN];
+    uint8_t cons[FR_WIN];
+    uint8_t valid[FR_WIN];
+    int wave_tot[FR_THREADS / kWave];
+    int nchunk;
+    int iter, niters, max_good, done, failed;
+    int attempts;        // attempts already spent on the iteration being drawn
+    long long pos;       // absolute index of the next unread RNG word
+    int scan_base;
+};
+
+__device__ __forceinline__ bool collinear_last(const float (&m)[7][2])
+{
+    // OpenCV haveCollinearPoints: last point against every earlier pair
+    const int i = 6;
+    for (int j = 0; j < i; j++) {
+        const double dx1 = m[j][0] - m[i][0], dy1 = m[j][1] - m[i][1];
+        for (int k = 0; k < j; k++) {
+            const double dx2 = m[k][0] - m[i][0], dy2 = m[k][1] - m[i][1];
+            if (fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                return true;
+        }
+    }
+    return false;
+}
+
+// draw one 7-subset starting at window offset o; returns draws consumed or 0
+// when the window ends first
+__device__ __forceinline__ int draw_subset(const uint16_t *r, int o, int (&idx)[7])
+{
+    int p = o;
+    for (int i = 0; i < 7; i++) {
+        for (;;) {
+            if (p >= FR_WIN) return 0;
+            const int v = r[p++];
+            bool dup = false;
+            for (int j = 0; j < i; j++) dup = dup || (idx[j] == v);
+            if (!dup) { idx[i] = v; break; }
+        }
+    }
+    return p - o;
+}
+
+__device__ int solve_cubic(const double (&c)[4], double (&r)[3])
+{
+    double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    double x0 = 0, x1 = 0, x2 = 0;
+    int n = 0;
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) n = a3 == 0 ? -1 : 0;
+            else { x0 = -a3 / a2; n = 1; }
+        } else {
+            double d = a2 * a2 - 4 * a1 * a3;
+            if (d >= 0) {
+                d = sqrt(d);
+                const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+                if (fabs(q1) > fabs(q2)) { x0 = q1 / a1; x1 = a3 / q1; }
+                else { x0 = q2 / a1; x1 = a3 / q2; }
+                n = d > 0 ? 2 : 1;
+            }
+        }
+    } else {
+        a0 = 1. / a0; a1 *= a0; a2 *= a0; a3 *= a0;
+        const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        const double Qcubed = Q * Q * Q;
+        double d = Qcubed - R * R;
+        if (d > 0) {
+            const double theta = acos(R / sqrt(Qcubed));
+            const double sqrtQ = sqrt(Q);
+            const double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+            x0 = t0 * cos(t1) - t2;
+            x1 = t0 * cos(t1 + (2. * 3.14159265358979323846 / 3)) - t2;
+            x2 = t0 * cos(t1 + (4. * 3.14159265358979323846 / 3)) - t2;
+            n = 3;
+        } else if (d == 0) {
+            if (R >= 0) { x0 = -2 * pow(R, 1. / 3) - a1 / 3; x1 = pow(R, 1. / 3) - a1 / 3; }
+            else { x0 = 2 * pow(-R, 1. / 3) - a1 / 3; x1 = -pow(-R, 1. / 3) - a1 / 3; }
+            n = 2;
+        } else {
+            d = sqrt(-d);
+            double e = pow(d + fabs(R), 1. / 3);
+            if (R > 0) e = -e;
+            x0 = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    r[0] = x0; r[1] = x1; r[2] = x2;
+    return n;
+}
+
+// 7-point solver (OpenCV run7Point semantics with Hartley normalisation); the
+// null-space basis comes from a Householder QR of A^T.  Returns 0..3 models.
+__device__ int solve_f7(const float (&m1)[7][2], const float (&m2)[7][2], double (*Fout)[9])
+{
+    double m1cx = 0, m1cy = 0, m2cx = 0, m2cy = 0, scale1 = 0, scale2 = 0;
+    const double t = 1. / 7;
+    for (int i = 0; i < 7; i++) {
+        m1cx += m1[i][0]; m1cy += m1[i][1];
+        m2cx += m2[i][0]; m2cy += m2[i][1];
+    }
+    m1cx *= t; m1cy *= t; m2cx *= t; m2cy *= t;
+    for (int i = 0; i < 7; i++) {
+        double dx = m1[i][0] - m1cx, dy = m1[i][1] - m1cy;
+        scale1 += sqrt(dx * dx + dy * dy);
+        dx = m2[i][0] - m2cx; dy = m2[i][1] - m2cy;
+        scale2 += sqrt(dx * dx + dy * dy);
+    }
+    scale1 *= t; scale2 *= t;
+    if (scale1 < FLT_EPSILON || scale2 < FLT_EPSILON) return 0;
+    scale1 = sqrt(2.) / scale1;
+    scale2 = sqrt(2.) / scale2;
+
+    double M[9][7];  // A^T
+    for (int i = 0; i < 7; i++) {
+        const double x0 = (m1[i][0] - m1cx) * scale1, y0 = (m1[i][1] - m1cy) * scale1;
+        const double x1 = (m2[i][0] - m2cx) * scale2, y1 = (m2[i][1] - m2cy) * scale2;
+        M[0][i] = x1 * x0; M[1][i] = x1 * y0; M[2][i] = x1;
+        M[3][i] = y1 * x0; M[4][i] = y1 * y0; M[5][i] = y1;
+        M[6][i] = x0; M[7][i] = y0; M[8][i] = 1;
+    }
+    double V[7][9], beta[7];
+    for (int k = 0; k < 7; k++) {
+        double s = 0;
+        for (int i = k; i < 9; i++) s += M[i][k] * M[i][k];
+        const double nrm = sqrt(s);
+        const double alpha = M[k][k] > 0 ? -nrm : nrm;
+        for (int i = 0; i < 9; i++) V[k][i] = 0;
+        for (int i = k; i < 9; i++) V[k][i] = M[i][k];
+        V[k][k] -= alpha;
+        double vn = 0;
+        for (int i = k; i < 9; i++) vn += V[k][i] * V[k][i];
+        beta[k] = vn > 0 ? 2.0 / vn : 0.0;
+        for (int j = k; j < 7; j++) {
+            double dot = 0;
+            for (int i = k; i < 9; i++) dot += V[k][i] * M[i][j];
+            dot *= beta[k];
+            for (int i = k; i < 9; i++) M[i][j] -= dot * V[k][i];
+        }
+    }
+    double f1[9], f2[9];
+    for (int c = 0; c < 2; c++) {
+        double q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        q[7 + c] = 1.0;
+        for (int k = 6; k >= 0; k--) {
+            double dot = 0;
+            for (int i = k; i < 9; i++) dot += V[k][i] * q[i];
+            dot *= beta[k];
+            for (int i = k; i < 9; i++) q[i] -= dot * V[k][i];
+        }
+        for (int i = 0; i < 9; i++) (c == 0 ? f1 : f2)[i] = q[i];
+    }
+
+    double c[4], r[3];
+    for (int i = 0; i < 9; i++) f1[i] -= f2[i];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7];
+    double t1 = f2[3] * f2[8] - f2[5] * f2[6];
+    double t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 -
+           f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) -
+           f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) -
+           f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7];
+    t1 = f1[3] * f1[8] - f1[5] * f1[6];
+    t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 -
+           f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) -
+           f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) -
+           f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+
+    const int n = solve_cubic(c, r);
+    if (n < 1 || n > 3) return n < 0 ? 0 : n;
+
+    const double T1[9] = {scale1, 0, -scale1 * m1cx, 0, scale1, -scale1 * m1cy, 0, 0, 1};
+    const double T2[9] = {scale2, 0, -scale2 * m2cx, 0, scale2, -scale2 * m2cy, 0, 0, 1};
+    for (int k = 0; k < n; k++) {
+        double Fn[9], tmp[9], F[9];
+        double lambda = r[k], mu = 1.;
+        const double s = f1[8] * r[k] + f2[8];
+        if (fabs(s) > DBL_EPSILON) { mu = 1. / s; lambda *= mu; Fn[8] = 1.; }
+        else Fn[8] = 0.;
+        for (int i = 0; i < 8; i++) Fn[i] = f1[i] * lambda + f2[i] * mu;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double acc = 0;
+                for (int l = 0; l < 3; l++) acc += T2[l * 3 + i] * Fn[l * 3 + j];
+                tmp[i * 3 + j] = acc;
+            }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double acc = 0;
+                for (int l = 0; l < 3; l++) acc += tmp[i * 3 + l] * T1[l * 3 + j];
+                F[i * 3 + j] = acc;
+            }
+        if (fabs(F[8]) > FLT_EPSILON) {
+            const double inv = 1. / F[8];
+            for (int i = 0; i < 9; i++) F[i] *= inv;
+        }
+        for (int i = 0; i < 9; i++) Fout[k][i] = F[i];
+    }
+    return n;
+}
+
+// larger of the two squared point-to-epipolar-line distances, as float
+__device__ __forceinline__ float f_error(const float4 p, const double *F)
+{
+    const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
+    double a = F[0] * x1 + F[1] * y1 + F[2];
+    double b = F[3] * x1 + F[4] * y1 + F[5];
+    double c = F[6] * x1 + F[7] * y1 + F[8];
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6];
+    b = F[1] * x2 + F[4] * y2 + F[7];
+    c = F[2] * x2 + F[5] * y2 + F[8];
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = x1 * a + y1 * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 > e2 ? e1 : e2);
+}
+
+__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : (p > 1 ? 1 : p);
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+__global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restrict__ good,
+                                                         const int *__restrict__ n_good, int kp_stride,
+                                                         const uint32_t *__restrict__ rng_raw, int rng_len,
+                                                         FRansacParams prm, uint8_t *__restrict__ mask,
+                                                         double *__restrict__ Fout, int *__restrict__ info,
+                                                         vo_match *__restrict__ final_m)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    FrShared &S = *reinterpret_cast<FrShared *>(s_dyn);
+    float4 *pts = reinterpret_cast<float4 *>(s_dyn + ((sizeof(FrShared) + 15) & ~size_t(15)));
+
+    const int pair = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(n_good[pair], kp_stride);
+    const vo_match *g = good + (size_t)pair * kp_stride;
+    uint8_t *msk = mask + (size_t)pair * kp_stride;
+    int *inf = info + pair * 4;
+
+    for (int i = tid; i < n; i += FR_THREADS) {
+        pts[i] = make_float4(g[i].px, g[i].py, g[i].cx, g[i].cy);
+        msk[i] = 0;
+    }
+    if (n < 15) {  // OpenCV would run LMedS here; reported as "not found"
+        if (tid == 0) { inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0; }
+        return;
+    }
+    if (tid == 0) {
+        S.iter = 0;
+        S.niters = prm.max_iters > 1 ? prm.max_iters : 1;
+        S.max_good = 0; S.done = 0; S.failed = 0; S.attempts = 0; S.pos = 0;
+    }
+    __syncthreads();
+
+    const float thr2 = (float)(prm.threshold * prm.threshold);
+
+    while (true) {
+        // 1. window of draws
+        const long long pos = S.pos;
+        for (int k = tid; k < FR_WIN; k += FR_THREADS) {
+            const long long a = pos + k;
+            S.r[k] = a < rng_len ? (uint16_t)(rng_raw[a] % (uint32_t)n) : (uint16_t)0;
+            if (a >= rng_len) S.cons[k] = 0;
+        }
+        __syncthreads();
+        // 2. one subset attempt per window offset
+        for (int o = tid; o < FR_WIN; o += FR_THREADS) {
+            int idx[7];
+            int cons = draw_subset(S.r, o, idx);
+            if (pos + o + cons > rng_len) cons = 0;
+            bool ok = false;
+            if (cons) {
+                float a[7][2], b[7][2];
+                for (int i = 0; i < 7; i++) {
+                    const float4 p = pts[idx[i]];
+                    a[i][0] = p.x; a[i][1] = p.y; b[i][0] = p.z; b[i][1] = p.w;
+                }
+                ok = !collinear_last(a) && !collinear_last(b);
+            }
+            S.cons[o] = (uint8_t)cons;
+            S.valid[o] = (uint8_t)ok;
+        }
+        __syncthreads();
+        // 3. chain offsets into iterations
+        if (tid == 0) {
+            int w = 0, nc = 0, att = S.attempts;
+            const int want = min(FR_CHUNK, S.niters - S.iter);
+            bool stuck = false;
+            while (nc < want && !stuck) {
+                for (;;) {
+                    if (w >= FR_WIN || S.cons[w] == 0) { stuck = true; break; }
+                    if (S.valid[w]) { S.start[nc++] = w; w += S.cons[w]; att = 0; break; }
+                    w += S.cons[w];
+                    if (++att >= FR_MAX_ATTEMPTS) { S.failed = 1; stuck = true; break; }
+                }
+            }
+            S.nchunk = nc;
+            S.attempts = att;
+            S.pos = pos + w;
+            if (nc == 0 && w == 0) S.failed = 1;  // RNG table exhausted: cannot progress
+        }
+        __syncthreads();
+        const int nc = S.nchunk;
+        // 4. solve
+        if (tid < nc) {
+            int idx[7];
+            draw_subset(S.r, S.start[tid], idx);
+            float a[7][2], b[7][2];
+            for (int i = 0; i < 7; i++) {
+                const float4 p = pts[idx[i]];
+                a[i][0] = p.x; a[i][1] = p.y; b[i][0] = p.z; b[i][1] = p.w;
+            }
+            S.nmodels[tid] = solve_f7(a, b, S.models[tid]);
+        }
+        __syncthreads();
+        // 5. score every candidate matrix: one wave per (iteration, model)
+        for (int hm = wave; hm < nc * 3; hm += FR_THREADS / kWave) {
+            const int h = hm / 3, m = hm - 3 * h;
+            if (m >= S.nmodels[h]) continue;
+            double F[9];
+            for (int i = 0; i < 9; i++) F[i] = S.models[h][m][i];
+            int cnt = 0;
+            for (int i = lane; i < n; i += kWave) cnt += (f_error(pts[i], F) <= thr2);
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (lane == 0) S.counts[h][m] = cnt;
+        }
+        __syncthreads();
+        // 6. sequential acceptance
+        if (tid == 0) {
+            for (int h = 0; h < nc; h++) {
+                const int nm = S.nmodels[h];
+                for (int m = 0; m < nm; m++) {
+                    const int goodc = S.counts[h][m];
+                    if (goodc > max(S.max_good, 6)) {
+                        for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
+                        S.max_good = goodc;
+                        S.niters = ransac_update_num_iters(prm.confidence, (double)(n - goodc) / n, 7, S.niters);
+                    }
+                }
+                S.iter++;
+                if (S.iter >= S.niters) break;
+            }
+            if (S.iter >= S.niters) S.done = 1;
+            if (S.failed) S.done = 1;  // getSubset gave up: stop (iter == 0 -> nothing found)
+        }
+        __syncthreads();
+        if (S.done) break;
+    }
+
+    // final mask, then the motion filter with ordered compaction
+    const bool found = S.max_good > 0;
+    if (tid == 0) S.scan_base = 0;
+    __syncthreads();
+    double F[9];
+    for (int i = 0; i < 9; i++) F[i] = S.best[i];
+    int n_inl = 0;
+    vo_match *fm = final_m + (size_t)pair * kp_stride;
+    for (int i0 = 0; i0 < n; i0 += FR_THREADS) {
+        const int i = i0 + tid;
+        bool inl = false, keep = false;
+        if (i < n && found) {
+            inl = f_error(pts[i], F) <= thr2;
+            msk[i] = (uint8_t)inl;
+            const float dx = pts[i].z - pts[i].x, dy = pts[i].w - pts[i].y;
+            keep = inl && sqrtf(dx * dx + dy * dy) < 100.0f;
+        }
+        const uint64_t bm = __ballot(keep);
+        n_inl += __popcll(__ballot(inl));
+        if (lane == 0) S.wave_tot[wave] = __popcll(bm);
+        __syncthreads();
+        int off = S.scan_base;
+        for (int w = 0; w < wave; w++) off += S.wave_tot[w];
+        if (keep) fm[off + __popcll(bm & ((1ull << lane) - 1ull))] = g[i];
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < FR_THREADS / kWave; w++) tot += S.wave_tot[w];
+            S.scan_base += tot;
+        }
+        __syncthreads();
+    }
+    // per-wave inlier totals -> block total
+    if (lane == 0) S.wave_tot[wave] = n_inl;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < FR_THREADS / kWave; w++) tot += S.wave_tot[w];
+        inf[0] = found ? 1 : 0;
+        inf[1] = S.iter;
+        inf[2] = tot;
+        inf[3] = S.scan_base;
+        double *Fo = Fout + (size_t)pair * 9;
+        for (int i = 0; i < 9; i++) Fo[i] = found ? S.best[i] : 0.0;
+    }
+}
+
+void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride, const uint32_t *rng_raw,
+                     int rng_len, FRansacParams prm, uint8_t *mask, double *F, int *info, vo_match *final_m,
+                     int pairs, hipStream_t s)
+{
+    const size_t lds = ((sizeof(FrShared) + 15) & ~size_t(15)) + sizeof(float4) * (size_t)kp_stride;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_f_ransac),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_f_ransac, dim3(pairs), dim3(FR_THREADS), lds, s, good, n_good, kp_stride, rng_raw,
+                       rng_len, prm, mask, F, info, final_m);
+}
+
+}  // namespace vo

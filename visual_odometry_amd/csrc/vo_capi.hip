@@ -1,0 +1,390 @@
+// C ABI of libvo_hip.so (declared in include/vo_hip.h): context management
+// and the single-frame operators.  Device work is enqueued on the context's
+// stream through the launchers of vo_internal.h; there is no host fallback.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vo_orb_pattern.h"
+#include "vo_ctx.h"
+
+using namespace vo;
+
+static thread_local std::string g_create_error;
+
+static int fail(vo_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, VO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// cv::RNG with seed 2^64-1: the raw 32-bit words are the same for every call,
+// so they are tabulated once (reference src/feature_matcher.cpp:54 reaches
+// RANSACPointSetRegistrator::run, which constructs RNG((uint64)-1)).
+static void fill_rng_table(std::vector<uint32_t> &t)
+{
+    uint64_t state = ~0ull;
+    for (auto &w : t) {
+        state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+        w = (uint32_t)state;
+    }
+}
+
+// ORB's sampling pattern rotated by the angle FAST keypoints carry (-1 degree,
+// i.e. cv::KeyPoint's "not applicable"), exactly as computeOrbDescriptors does:
+// float a = (float)cos(angle), b = (float)sin(angle), cvRound of x*a - y*b etc.
+static void build_pattern(float angle_deg, int8_t *out)
+{
+    float angle = angle_deg;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    const float a = (float)cos(angle), b = (float)sin(angle);
+    for (int i = 0; i < 512; i++) {
+        const float px = vo_orb_bit_pattern_31[2 * i], py = vo_orb_bit_pattern_31[2 * i + 1];
+        const float x = px * a - py * b, y = px * b + py * a;
+        out[2 * i] = (int8_t)lrint((double)x);
+        out[2 * i + 1] = (int8_t)lrint((double)y);
+    }
+}
+
+extern "C" {
+
+int vo_abi_version(void) { return 1; }
+
+const char *vo_last_error(const vo_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+vo_ctx *vo_create(int device, const vo_cfg *cfg)
+{
+    if (!cfg || cfg->max_width < 16 || cfg->max_height < 16 || cfg->max_width > kMaxDim ||
+        cfg->max_height > kMaxDim || (long long)cfg->max_width * cfg->max_height > (1ll << 24) ||
+        cfg->max_features < 1 || cfg->max_features > VO_MAX_FEATURES_LIMIT || cfg->max_batch < 1) {
+        fail(nullptr, VO_ERR_ARG, "vo_create: bad configuration");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        fail(nullptr, VO_ERR_HIP, "vo_create: no usable HIP device %d (found %d)", device, ndev);
+        return nullptr;
+    }
+    vo_ctx *c = new vo_ctx();
+    c->device = device;
+    c->cfg = *cfg;
+    c->gc = {3735, 19235, 9798, 15};
+    if (cfg->gray_shift > 0) c->gc = {cfg->gray_b, cfg->gray_g, cfg->gray_r, cfg->gray_shift};
+    int rc = c->allocate();
+    if (rc != VO_OK) {
+        g_create_error = c->err;
+        vo_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void vo_destroy(vo_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    c->release();
+    delete c;
+}
+
+}  // extern "C"
+
+int vo_ctx::allocate()
+{
+    vo_ctx *ctx = this;
+    HIP_TRY(ctx, hipSetDevice(device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int B = cfg.max_batch;
+    pitch = align_up(cfg.max_width, 128);
+    hpad = align_up(cfg.max_height, 16);
+    plane_bytes = (size_t)pitch * hpad;
+    kp_stride = align_up(cfg.max_features, 8);
+    slots = 2 * B + 2;
+    cand_cap = cfg.max_width * cfg.max_height / 4 + 64;
+    in_frame_bytes = (size_t)cfg.max_width * cfg.max_height * 4;
+
+    HIP_TRY(ctx, hipMalloc(&d_in, in_frame_bytes * B));
+    HIP_TRY(ctx, hipMalloc(&d_gray, plane_bytes * B));
+    HIP_TRY(ctx, hipMalloc(&d_score, plane_bytes * B));
+    HIP_TRY(ctx, hipMalloc(&d_blur, plane_bytes * B));
+    HIP_TRY(ctx, hipMalloc(&d_cand, sizeof(uint32_t) * (size_t)cand_cap * B));
+    HIP_TRY(ctx, hipMalloc(&d_cand_count, sizeof(uint32_t) * B));
+    HIP_TRY(ctx, hipMalloc(&d_kps, sizeof(vo_kp) * (size_t)kp_stride * slots));
+    HIP_TRY(ctx, hipMalloc(&d_desc, (size_t)32 * kp_stride * slots));
+    HIP_TRY(ctx, hipMalloc(&d_nkp, sizeof(int) * slots));
+    HIP_TRY(ctx, hipMalloc(&d_pattern, 1024));
+    HIP_TRY(ctx, hipMalloc(&d_partial, sizeof(uint2) * (size_t)kKnnSplits * kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_knn, sizeof(vo_knn2) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_good, sizeof(vo_match) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_ngood, sizeof(int) * B));
+    HIP_TRY(ctx, hipMalloc(&d_mask, (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_F, sizeof(double) * 9 * B));
+    HIP_TRY(ctx, hipMalloc(&d_info, sizeof(int) * 4 * B));
+    HIP_TRY(ctx, hipMalloc(&d_final, sizeof(vo_match) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_qslot, sizeof(int) * B));
+    HIP_TRY(ctx, hipMalloc(&d_tslot, sizeof(int) * B));
+    HIP_TRY(ctx, hipMemset(d_nkp, 0, sizeof(int) * slots));
+    HIP_TRY(ctx, hipMemset(d_score, 0, plane_bytes * B));
+
+    std::vector<uint32_t> rng(1 << 16);
+    fill_rng_table(rng);
+    rng_len = (int)rng.size();
+    HIP_TRY(ctx, hipMalloc(&d_rng, sizeof(uint32_t) * rng.size()));
+    HIP_TRY(ctx, hipMemcpy(d_rng, rng.data(), sizeof(uint32_t) * rng.size(), hipMemcpyHostToDevice));
+
+    int8_t pat[1024];
+    build_pattern(-1.0f, pat);
+    HIP_TRY(ctx, hipMemcpy(d_pattern, pat, 1024, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipHostMalloc(&h_pinned, kPinnedBytes));
+    return VO_OK;
+}
+
+void vo_ctx::release()
+{
+    void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_count, d_kps, d_desc, d_nkp, d_pattern,
+                    d_partial, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (h_pinned) hipHostFree(h_pinned);
+    if (stream) hipStreamDestroy(stream);
+}
+
+static int check_frame(vo_ctx *c, int w, int h, const char *who)
+{
+    if (!c) return VO_ERR_ARG;
+    if (w < 7 || h < 7 || w > c->cfg.max_width || h > c->cfg.max_height)
+        return fail(c, VO_ERR_ARG, "%s: frame %dx%d outside the context limits %dx%d", who, w, h,
+                    c->cfg.max_width, c->cfg.max_height);
+    return VO_OK;
+}
+
+static int finish(vo_ctx *c, const char *who)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(c, VO_ERR_HIP, "%s: %s", who, hipGetErrorString(e));
+    return VO_OK;
+}
+
+// copy a user image (host or device, any stride) into the packed staging area
+static int stage_image(vo_ctx *c, const uint8_t *src, int row_bytes, int h, int stride)
+{
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_in, row_bytes, src, stride, row_bytes, h, hipMemcpyDefault, c->stream));
+    return VO_OK;
+}
+
+extern "C" {
+
+int vo_gray(vo_ctx *c, const uint8_t *src, int w, int h, int src_stride, int channels, uint8_t *dst,
+            int dst_stride)
+{
+    int rc = check_frame(c, w, h, "vo_gray");
+    if (rc) return rc;
+    if (!src || !dst || (channels != 3 && channels != 4) || src_stride < w * channels || dst_stride < w)
+        return fail(c, VO_ERR_ARG, "vo_gray: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = stage_image(c, src, w * channels, h, src_stride))) return rc;
+    launch_gray(c->d_in, w, h, w * channels, 0, channels, c->plane(c->d_gray), 1, c->gc, c->stream);
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->d_gray, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    return finish(c, "vo_gray");
+}
+
+int vo_fast_score(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int threshold, uint8_t *score,
+                  int score_stride)
+{
+    int rc = check_frame(c, w, h, "vo_fast_score");
+    if (rc) return rc;
+    if (!gray || !score || stride < w || score_stride < w) return fail(c, VO_ERR_ARG, "vo_fast_score: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = stage_image(c, gray, w, h, stride))) return rc;
+    launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, c->plane(c->d_score),
+                    PlaneBatch{nullptr, 0, 0}, threshold, 1, c->gc, c->stream);
+    HIP_TRY(c, hipMemcpy2DAsync(score, score_stride, c->d_score, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    return finish(c, "vo_fast_score");
+}
+
+int vo_blur7(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, uint8_t *dst, int dst_stride)
+{
+    int rc = check_frame(c, w, h, "vo_blur7");
+    if (rc) return rc;
+    if (!gray || !dst || stride < w || dst_stride < w) return fail(c, VO_ERR_ARG, "vo_blur7: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = stage_image(c, gray, w, h, stride))) return rc;
+    launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
+                    c->plane(c->d_blur), 0, 1, c->gc, c->stream);
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->d_blur, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    return finish(c, "vo_blur7");
+}
+
+int vo_detect(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int max_features, int fast_threshold,
+              vo_kp *kps, uint8_t *desc, int *n_out)
+{
+    int rc = check_frame(c, w, h, "vo_detect");
+    if (rc) return rc;
+    if (!gray || !kps || !desc || !n_out || stride < w || max_features < 1 ||
+        max_features > c->cfg.max_features)
+        return fail(c, VO_ERR_ARG, "vo_detect: bad arguments (max_features %d, context limit %d)",
+                    max_features, c->cfg.max_features);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = stage_image(c, gray, w, h, stride))) return rc;
+    c->enqueue_detect(c->d_in, w, h, w, 0, 1, max_features, fast_threshold, 1, /*first_slot=*/0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_nkp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = finish(c, "vo_detect"))) return rc;
+    const int n = *reinterpret_cast<int *>(c->h_pinned);
+    *n_out = n;
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpy(kps, c->d_kps, sizeof(vo_kp) * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(desc, c->d_desc, (size_t)32 * n, hipMemcpyDefault));
+    }
+    return VO_OK;
+}
+
+static int upload_features(vo_ctx *c, int slot, const vo_kp *kps, const uint8_t *desc, int n)
+{
+    if (kps) HIP_TRY(c, hipMemcpyAsync(c->d_kps + (size_t)slot * c->kp_stride, kps, sizeof(vo_kp) * n,
+                                      hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_desc + (size_t)slot * c->kp_stride * 32, desc, (size_t)32 * n,
+                              hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_nkp + slot, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // &n is a stack variable
+    return VO_OK;
+}
+
+static int set_single_pair(vo_ctx *c)
+{
+    const int q = 0, t = 1;
+    HIP_TRY(c, hipMemcpy(c->d_qslot, &q, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tslot, &t, sizeof(int), hipMemcpyHostToDevice));
+    return VO_OK;
+}
+
+int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *train, int nt, vo_knn2 *out)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!query || !train || !out || nq < 0 || nt < 0 || nq > c->cfg.max_features || nt > c->cfg.max_features)
+        return fail(c, VO_ERR_ARG, "vo_knn2_hamming: bad arguments (nq %d, nt %d, limit %d)", nq, nt,
+                    c->cfg.max_features);
+    if (nq == 0) return VO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = upload_features(c, 0, nullptr, query, nq))) return rc;
+    if ((rc = upload_features(c, 1, nullptr, train, nt))) return rc;
+    if ((rc = set_single_pair(c))) return rc;
+    launch_knn2(c->d_desc, (size_t)c->kp_stride * 32, c->d_nkp, c->d_qslot, c->d_tslot, c->kp_stride,
+                c->d_partial, c->kp_stride, 1, c->stream);
+    launch_match_finalize(c->d_partial, c->d_kps, c->kp_stride, c->d_nkp, c->d_qslot, c->d_tslot, 0.7f,
+                          c->d_knn, c->d_good, c->d_ngood, 1, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_knn, sizeof(vo_knn2) * nq, hipMemcpyDefault, c->stream));
+    return finish(c, "vo_knn2_hamming");
+}
+
+int vo_find_fundamental_ransac(vo_ctx *c, const float *p1, const float *p2, int n, double threshold,
+                               double confidence, int max_iters, uint8_t *mask, double *F, int *found,
+                               int *iters_run)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!p1 || !p2 || !mask || n < 0 || n > c->cfg.max_features)
+        return fail(c, VO_ERR_ARG, "vo_find_fundamental_ransac: bad arguments (n %d, limit %d)", n,
+                    c->cfg.max_features);
+    if (n < 15)
+        return fail(c, VO_ERR_UNSUPPORTED,
+                    "vo_find_fundamental_ransac: %d points (< 15) would take OpenCV's LMedS branch", n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (threshold <= 0) threshold = 3;
+    if (confidence < 2.220446049250313e-16 || confidence > 1 - 2.220446049250313e-16) confidence = 0.99;
+    std::vector<float> a(2 * (size_t)n), b(2 * (size_t)n);
+    HIP_TRY(c, hipMemcpy(a.data(), p1, sizeof(float) * 2 * n, hipMemcpyDefault));
+    HIP_TRY(c, hipMemcpy(b.data(), p2, sizeof(float) * 2 * n, hipMemcpyDefault));
+    std::vector<vo_match> g((size_t)n);
+    for (int i = 0; i < n; i++) {
+        g[i].query = i; g[i].train = i; g[i].distance = 0;
+        g[i].px = a[2 * i]; g[i].py = a[2 * i + 1];
+        g[i].cx = b[2 * i]; g[i].cy = b[2 * i + 1];
+    }
+    HIP_TRY(c, hipMemcpy(c->d_good, g.data(), sizeof(vo_match) * n, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ngood, &n, sizeof(int), hipMemcpyHostToDevice));
+    launch_f_ransac(c->d_good, c->d_ngood, c->kp_stride, c->d_rng, c->rng_len,
+                    FRansacParams{threshold, confidence, max_iters}, c->d_mask, c->d_F, c->d_info, c->d_final,
+                    1, c->stream);
+    int rc = finish(c, "vo_find_fundamental_ransac");
+    if (rc) return rc;
+    int info[4];
+    HIP_TRY(c, hipMemcpy(info, c->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(mask, c->d_mask, n, hipMemcpyDefault));
+    if (F) HIP_TRY(c, hipMemcpy(F, c->d_F, sizeof(double) * 9, hipMemcpyDefault));
+    if (found) *found = info[0];
+    if (iters_run) *iters_run = info[1];
+    return VO_OK;
+}
+
+int vo_match_features(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_desc, int n_prev, const vo_kp *curr_kps,
+             const uint8_t *curr_desc, int n_curr, float ratio, vo_match *out, int *n_out)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!n_out || n_prev < 0 || n_curr < 0 || n_prev > c->cfg.max_features || n_curr > c->cfg.max_features)
+        return fail(c, VO_ERR_ARG, "vo_match_features: bad arguments");
+    *n_out = 0;
+    // reference src/feature_matcher.cpp:21-23: empty in, empty out
+    if (n_prev == 0 || n_curr == 0) return VO_OK;
+    if (!prev_kps || !prev_desc || !curr_kps || !curr_desc || !out)
+        return fail(c, VO_ERR_ARG, "vo_match_features: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = upload_features(c, 0, prev_kps, prev_desc, n_prev))) return rc;
+    if ((rc = upload_features(c, 1, curr_kps, curr_desc, n_curr))) return rc;
+    if ((rc = set_single_pair(c))) return rc;
+    c->enqueue_match(1, ratio, FRansacParams{3.0, 0.99, 1000});
+    if ((rc = finish(c, "vo_match_features"))) return rc;
+    int info[4];
+    HIP_TRY(c, hipMemcpy(info, c->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    *n_out = info[3];
+    if (info[3] > 0) HIP_TRY(c, hipMemcpy(out, c->d_final, sizeof(vo_match) * info[3], hipMemcpyDefault));
+    return VO_OK;
+}
+
+}  // extern "C"
+
+// ---- shared enqueue helpers ------------------------------------------------
+
+void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
+                            int channels, int max_features, int fast_threshold, int batch, int first_slot)
+{
+    (void)hipMemsetAsync(d_cand_count, 0, sizeof(uint32_t) * batch, stream);
+    launch_frontend(src, w, h, src_stride, src_frame_stride, channels, PlaneBatch{nullptr, 0, 0},
+                    plane(d_score), plane(d_blur), fast_threshold, batch, gc, stream);
+    launch_nms_emit(plane(d_score), w, h, d_cand, d_cand_count, cand_cap, batch, stream);
+    launch_select(d_cand, d_cand_count, cand_cap, w, h, max_features, kFBorder,
+                  d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot, batch, stream);
+    launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
+                 d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
+}
+
+void vo_ctx::enqueue_match(int pairs, float ratio, FRansacParams prm)
+{
+    launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
+                pairs, stream);
+    launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio, d_knn, d_good,
+                          d_ngood, pairs, stream);
+    launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
+                    stream);
+}

@@ -1,0 +1,56 @@
+// Device-side state of one vo_ctx.
+#pragma once
+
+#include <string>
+
+#include "vo_internal.h"
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    vo_cfg cfg{};
+    vo::GrayCoeffs gc{};
+    std::string err;
+
+    // geometry of the internal planes: rows padded to whole 128x16 tiles
+    int pitch = 0, hpad = 0;
+    size_t plane_bytes = 0;
+    size_t in_frame_bytes = 0;
+    int kp_stride = 0;  // feature records per slot
+    int slots = 0;      // feature slots (keypoints + descriptors + count)
+    int cand_cap = 0;   // NMS survivors per frame: at most one per 2x2 block
+
+    uint8_t *d_in = nullptr;     // staging for frames handed over from the host
+    uint8_t *d_gray = nullptr, *d_score = nullptr, *d_blur = nullptr;
+    uint32_t *d_cand = nullptr, *d_cand_count = nullptr;
+    vo_kp *d_kps = nullptr;
+    uint8_t *d_desc = nullptr;
+    int *d_nkp = nullptr;
+    int8_t *d_pattern = nullptr;
+    uint2 *d_partial = nullptr;
+    vo_knn2 *d_knn = nullptr;
+    vo_match *d_good = nullptr;
+    int *d_ngood = nullptr;
+    uint8_t *d_mask = nullptr;
+    double *d_F = nullptr;
+    int *d_info = nullptr;
+    vo_match *d_final = nullptr;
+    int *d_qslot = nullptr, *d_tslot = nullptr;
+    uint32_t *d_rng = nullptr;
+    int rng_len = 0;
+
+    static constexpr size_t kPinnedBytes = 1 << 20;
+    void *h_pinned = nullptr;
+
+    vo::PlaneBatch plane(uint8_t *base) const { return vo::PlaneBatch{base, pitch, plane_bytes}; }
+
+    int allocate();
+    void release();
+
+    // gray/BGR frames already on the device -> keypoints + descriptors in
+    // feature slots first_slot .. first_slot+batch-1
+    void enqueue_detect(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
+                        int channels, int max_features, int fast_threshold, int batch, int first_slot);
+    // kNN-2 + ratio + F-RANSAC + motion filter for `pairs` (d_qslot/d_tslot) pairs
+    void enqueue_match(int pairs, float ratio, vo::FRansacParams prm);
+};

@@ -1,0 +1,90 @@
+// Internal declarations shared by the kernel translation units and the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vo_hip.h"
+
+namespace vo {
+
+constexpr int kWave = 64;
+constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
+constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
+constexpr int kKnnSplits = 4;      // train-set splits per query block
+constexpr int kFBorder = 31;       // ORB edgeThreshold
+
+// gray conversion weights (B, G, R, shift)
+struct GrayCoeffs {
+    int b, g, r, shift;
+};
+
+// A batch of equally sized 8-bit planes: plane i starts at base + i*plane_stride.
+struct PlaneBatch {
+    uint8_t *base;
+    int pitch;            // bytes per row
+    size_t plane_stride;  // bytes between consecutive planes
+};
+
+// ---- launchers (each enqueues on `s`, no sync) ---------------------------
+
+// BGR/BGRA -> gray for `batch` frames; src rows are src_stride bytes apart,
+// frames src_frame_stride bytes apart.
+void launch_gray(const uint8_t *src, int width, int height, int src_stride,
+                 size_t src_frame_stride, int channels, PlaneBatch dst,
+                 int batch, GrayCoeffs c, hipStream_t s);
+
+// Fused tile kernel: (optional BGR[A]->gray) + FAST-9/16 corner score map +
+// 7x7 fixed-point Gaussian.  Any of gray_out/score/blur may have base == 0.
+void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
+                     size_t src_frame_stride, int channels, PlaneBatch gray_out,
+                     PlaneBatch score, PlaneBatch blur, int threshold,
+                     int batch, GrayCoeffs c, hipStream_t s);
+
+// 3x3 strict non-max suppression over the score map; survivors are appended
+// to cand[frame*cand_cap ...] as keys ((255-score) << 24) | (y*width + x).
+void launch_nms_emit(PlaneBatch score, int width, int height, uint32_t *cand,
+                     uint32_t *cand_count, int cand_cap, int batch,
+                     hipStream_t s);
+
+// Keep the max_features best keys per frame (all of them, in raster order,
+// when there are not more than max_features), drop keypoints closer than
+// `border` px to the image edge, write vo_kp records.
+void launch_select(const uint32_t *cand, const uint32_t *cand_count,
+                   int cand_cap, int width, int height, int max_features,
+                   int border, vo_kp *kps, int kp_stride, int *nkp,
+                   int batch, hipStream_t s);
+
+// rBRIEF-256 on the blurred plane with a fixed integer pattern
+// (512 x (dx, dy) int8 in device memory).
+void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride,
+                  const int *nkp, const int8_t *pattern, uint8_t *desc,
+                  int batch, hipStream_t s);
+
+// Hamming kNN-2. For pair p the query set is (q_desc + q_slot[p]*slot_stride,
+// n[q_slot[p]]) and the train set likewise. partial: [pair][split][kp_stride] uint2.
+void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp,
+                 const int *q_slot, const int *t_slot, int kp_stride,
+                 uint2 *partial, int max_n, int pairs, hipStream_t s);
+
+// Merge the split partials into vo_knn2 records, apply the ratio test and
+// write the surviving matches in query order.
+void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride,
+                           const int *nkp, const int *q_slot, const int *t_slot,
+                           float ratio, vo_knn2 *knn, vo_match *good,
+                           int *n_good, int pairs, hipStream_t s);
+
+struct FRansacParams {
+    double threshold, confidence;
+    int max_iters;
+};
+
+// 7-point fundamental-matrix RANSAC per pair over good[pair*kp_stride ..],
+// followed by the 100 px motion filter.  Outputs: mask (per ratio survivor),
+// F (9 doubles), info = {found, iters_run, n_inliers, n_final}, final matches.
+void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride,
+                     const uint32_t *rng_raw, int rng_len, FRansacParams prm,
+                     uint8_t *mask, double *F, int *info, vo_match *final_m,
+                     int pairs, hipStream_t s);
+
+}  // namespace vo

@@ -1,0 +1,172 @@
+"""Seeded synthetic camera sequences for tests and benchmarks.
+
+A textured height-field scene (value noise plus random rectangles and discs)
+is viewed by a pinhole camera that moves a little between frames, so every
+frame pair has a known relative pose, a consistent epipolar geometry and a
+float32 depth map in millimetres -- the same kind of input the reference node
+receives from the ZED camera (reference src/zed_interface.cpp:66-94: BGRA8
+left image + float32 depth in mm).
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+__all__ = ["Camera", "Scene", "make_sequence", "CONFIG_CAMERAS"]
+
+
+@dataclasses.dataclass(frozen=True)
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+
+# intrinsics used by the benchmark configurations
+CONFIG_CAMERAS = {
+    "vga": Camera(640, 480, 525.0, 525.0, 319.5, 239.5),
+    "hd720": Camera(1280, 720, 700.0, 700.0, 639.5, 359.5),
+    "hd1080": Camera(1920, 1080, 1050.0, 1050.0, 959.5, 539.5),
+    "kitti": Camera(1241, 376, 718.856, 718.856, 607.19, 185.22),
+}
+
+
+def _value_noise(rng, shape, period):
+    gh, gw = shape[0] // period + 3, shape[1] // period + 3
+    grid = rng.random((gh, gw), dtype=np.float32)
+    ys = np.arange(shape[0], dtype=np.float32) / period
+    xs = np.arange(shape[1], dtype=np.float32) / period
+    y0 = ys.astype(np.int32)
+    x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    fy = fy * fy * (3 - 2 * fy)
+    fx = fx * fx * (3 - 2 * fx)
+    g00 = grid[y0][:, x0]
+    g01 = grid[y0][:, x0 + 1]
+    g10 = grid[y0 + 1][:, x0]
+    g11 = grid[y0 + 1][:, x0 + 1]
+    return (g00 * (1 - fx) + g01 * fx) * (1 - fy) + (g10 * (1 - fx) + g11 * fx) * fy
+
+
+class Scene:
+    """Textured surface z = Z(u, v) (millimetres) with texture T(u, v)."""
+
+    MM_PER_TEXEL = 4.0
+
+    def __init__(self, seed: int, extent_mm=(16000.0, 10000.0), n_shapes: int = 900):
+        rng = np.random.default_rng(seed)
+        tw = int(extent_mm[0] / self.MM_PER_TEXEL)
+        th = int(extent_mm[1] / self.MM_PER_TEXEL)
+        tex = np.full((th, tw), 128.0, dtype=np.float32)
+        for period, amp in ((64, 40.0), (16, 36.0), (5, 30.0)):
+            tex += amp * (_value_noise(rng, (th, tw), period) - 0.5) * 2.0
+        for _ in range(n_shapes):
+            cx, cy = rng.integers(0, tw), rng.integers(0, th)
+            w, h = rng.integers(6, 90), rng.integers(6, 90)
+            val = float(rng.integers(10, 246))
+            if rng.random() < 0.5:
+                tex[max(0, cy - h):cy + h, max(0, cx - w):cx + w] = val
+            else:
+                r = int(min(w, h))
+                yy, xx = np.ogrid[-r:r + 1, -r:r + 1]
+                y0, x0 = max(0, cy - r), max(0, cx - r)
+                sub = tex[y0:cy + r + 1, x0:cx + r + 1]
+                m = (yy * yy + xx * xx <= r * r)[(y0 - (cy - r)):(y0 - (cy - r)) + sub.shape[0],
+                                                 (x0 - (cx - r)):(x0 - (cx - r)) + sub.shape[1]]
+                sub[m] = val
+        self.tex = np.clip(tex, 0, 255)
+        self.extent = extent_mm
+        self.seed = seed
+
+    @staticmethod
+    def surface(u, v):
+        return (3500.0 + 900.0 * np.sin(u / 1500.0) * np.cos(v / 1200.0)
+                + 250.0 * np.sin(u / 500.0 + v / 700.0))
+
+    def sample(self, u, v):
+        tx = (u + self.extent[0] / 2) / self.MM_PER_TEXEL
+        ty = (v + self.extent[1] / 2) / self.MM_PER_TEXEL
+        th, tw = self.tex.shape
+        tx = np.clip(tx, 0, tw - 1.001)
+        ty = np.clip(ty, 0, th - 1.001)
+        x0 = tx.astype(np.int32)
+        y0 = ty.astype(np.int32)
+        fx = (tx - x0).astype(np.float32)
+        fy = (ty - y0).astype(np.float32)
+        t = self.tex
+        return ((t[y0, x0] * (1 - fx) + t[y0, x0 + 1] * fx) * (1 - fy)
+                + (t[y0 + 1, x0] * (1 - fx) + t[y0 + 1, x0 + 1] * fx) * fy)
+
+    def render(self, cam: Camera, R: np.ndarray, c: np.ndarray):
+        """Render gray (float32) and depth (float32 mm) for world->camera Xc = R (Xw - c)."""
+        xs = (np.arange(cam.width, dtype=np.float64) - cam.cx) / cam.fx
+        ys = (np.arange(cam.height, dtype=np.float64) - cam.cy) / cam.fy
+        dx, dy = np.meshgrid(xs, ys)
+        Rt = R.T
+        wx = Rt[0, 0] * dx + Rt[0, 1] * dy + Rt[0, 2]
+        wy = Rt[1, 0] * dx + Rt[1, 1] * dy + Rt[1, 2]
+        wz = Rt[2, 0] * dx + Rt[2, 1] * dy + Rt[2, 2]
+        s = np.full_like(dx, 3500.0)
+        for _ in range(12):
+            u = c[0] + s * wx
+            v = c[1] + s * wy
+            z = c[2] + s * wz
+            s = s + 0.8 * (self.surface(u, v) - z) / wz
+        u = c[0] + s * wx
+        v = c[1] + s * wy
+        return self.sample(u, v).astype(np.float32), s.astype(np.float32)
+
+
+def _rot(rx, ry, rz):
+    cx_, sx = np.cos(rx), np.sin(rx)
+    cy_, sy = np.cos(ry), np.sin(ry)
+    cz_, sz = np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx_, -sx], [0, sx, cx_]])
+    Ry = np.array([[cy_, 0, sy], [0, 1, 0], [-sy, 0, cy_]])
+    Rz = np.array([[cz_, -sz, 0], [sz, cz_, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
+                  noise_sigma: float = 2.0, scene: Scene | None = None):
+    """Return dict with 'frames' (n,H,W,C uint8 BGR[A] or n,H,W gray when channels==1),
+    'depth' (n,H,W float32 mm), 'poses' (list of (R, c)) and 'camera'."""
+    scene = scene or Scene(seed)
+    rng = np.random.default_rng(seed + 7919)
+    frames, depths, poses = [], [], []
+    for k in range(n_frames):
+        R = _rot(np.deg2rad(0.10 * k), np.deg2rad(0.25 * k), np.deg2rad(0.12 * k))
+        c = np.array([14.0 * k, 4.0 * k, 30.0 * k])
+        gray, depth = scene.render(cam, R, c)
+        gray = gray + rng.normal(0.0, noise_sigma, gray.shape).astype(np.float32)
+        g8 = np.clip(np.rint(gray), 0, 255).astype(np.uint8)
+        if channels == 1:
+            frames.append(g8)
+        else:
+            img = np.empty(g8.shape + (channels,), dtype=np.uint8)
+            d = rng.integers(-3, 4, size=g8.shape + (2,), dtype=np.int16)
+            img[..., 1] = g8
+            img[..., 0] = np.clip(g8.astype(np.int16) + d[..., 0], 0, 255).astype(np.uint8)
+            img[..., 2] = np.clip(g8.astype(np.int16) + d[..., 1], 0, 255).astype(np.uint8)
+            if channels == 4:
+                img[..., 3] = 255
+            frames.append(img)
+        depths.append(depth)
+        poses.append((R, c))
+    return {"frames": np.stack(frames), "depth": np.stack(depths), "poses": poses,
+            "camera": cam}
+
+
+def relative_pose(pose_prev, pose_curr):
+    """T_prev_from_curr: X_prev = R X_curr + t (what the reference's PnP returns,
+    reference src/vo_node.cpp:698-706)."""
+    Rp, cp = pose_prev
+    Rc, cc = pose_curr
+    R = Rp @ Rc.T
+    t = Rp @ (cc - cp)
+    return R, t
