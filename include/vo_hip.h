@@ -139,6 +139,79 @@ int vo_match_features(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev_de
              int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
              int n_curr, float ratio, vo_match *out, int *n_out);
 
+/* cv::solvePnPRansac(obj, img, K, dist = 0, rvec, tvec, false, iters,
+ * reproj_threshold, confidence, inliers) followed by nothing else (the caller
+ * applies cv::Rodrigues): EPnP on 5-point samples drawn with cv::RNG seed
+ * 2^64-1, squared reprojection error <= threshold^2, adaptive iteration count,
+ * then solvePnP(SOLVEPNP_ITERATIVE) on the inliers.
+ * obj: n x 3 float32, img: n x 2 float32; rvec, tvec: 3 doubles each;
+ * inliers: up to n ascending indices.  *success is 0 when no hypothesis has
+ * more than 4 inliers, when n < 5 (OpenCV would use P3P for n == 4), or when
+ * the inlier set cannot seed the iterative solver (fewer than 6 / planar).
+ * reference src/frame_processor.cpp:176-196 */
+int vo_solve_pnp_ransac(vo_ctx *ctx, const float *obj, const float *img, int n,
+                        double fx, double fy, double cx, double cy, int iters,
+                        double reproj_threshold, double confidence,
+                        double *rvec, double *tvec, int32_t *inliers,
+                        int *n_inliers, int *success);
+
+/* ---- batched pipeline (throughput path) ------------------------------
+ *
+ * FrameProcessor::processFrame for n_streams independent camera streams,
+ * frames_per_stream consecutive frames of each per call
+ * (reference src/frame_processor.cpp:18-202).  Frame f of stream s is batch
+ * entry s*frames_per_stream + f.  Within a stream every frame is matched
+ * against its predecessor; the first frame of a call is matched against the
+ * last frame of the previous call (device-resident state), unless the stream
+ * was just configured or reset, in which case it is a "first frame" with no
+ * matching, exactly like processFrame(first_frame = true). */
+
+typedef struct {
+    int width, height, channels;      /* channels: 1 gray, 3 BGR, 4 BGRA */
+    int n_streams, frames_per_stream; /* product <= vo_cfg.max_batch */
+    int max_features, fast_threshold; /* the reference runs 1000 / 20 */
+    float ratio;                      /* Lowe ratio, reference 0.7f */
+    double f_threshold, f_confidence; /* reference 3.0, 0.99 */
+    int f_max_iters;                  /* OpenCV default 1000 */
+    int enable_pose;                  /* depth back-projection + PnP */
+    double fx, fy, cx, cy;            /* CameraParams */
+    int pnp_iters;                    /* reference 100 */
+    double pnp_threshold, pnp_confidence; /* reference 8.0, 0.99 */
+} vo_batch_cfg;
+
+typedef struct {
+    int32_t n_keypoints;  /* Features.keypoints.size() */
+    int32_t n_ratio;      /* ratio-test survivors */
+    int32_t f_found, f_iters, f_inliers;
+    int32_t n_matches;    /* after F-RANSAC + motion filter (FeatureMatcher::match) */
+    int32_t n_tracked;    /* after the multi-view (track age) filter */
+    int32_t n_3d;         /* with valid depth */
+    int32_t pnp_success, pnp_inliers, pnp_iters, pnp_points;
+    double rvec[3], tvec[3]; /* T_prev_from_curr, translation in depth units (mm) */
+} vo_frame_result;
+
+int vo_batch_configure(vo_ctx *ctx, const vo_batch_cfg *cfg);
+/* the next frame of every stream becomes a first frame */
+int vo_batch_reset(vo_ctx *ctx);
+/* Enqueue one batch. frames: batch x height x row_stride bytes, consecutive
+ * frames frame_stride bytes apart; depth (may be NULL): float32 mm, strides
+ * in elements.  Device pointers are read in place; host pointers are copied
+ * to the device first.  Returns without waiting for the GPU. */
+int vo_batch_submit(vo_ctx *ctx, const uint8_t *frames, int row_stride,
+                    size_t frame_stride, const float *depth,
+                    int depth_row_stride, size_t depth_frame_stride);
+/* Wait for the submitted batch; results: batch entries (host memory). */
+int vo_batch_wait(vo_ctx *ctx, vo_frame_result *results);
+/* Per-frame outputs of the last completed batch (host or device pointers;
+ * any may be NULL).  kps/desc hold up to max_features entries. */
+int vo_batch_get_features(vo_ctx *ctx, int frame, vo_kp *kps, uint8_t *desc,
+                          int *n_out);
+/* which: 0 = FeatureMatcher::match output, 1 = after the track-age filter,
+ * 2 = with valid depth (the PnP input).  pts3 (n x 3 float32) only for 2. */
+int vo_batch_get_matches(vo_ctx *ctx, int frame, int which, vo_match *out,
+                         float *pts3, int *n_out);
+int vo_batch_get_inliers(vo_ctx *ctx, int frame, int32_t *inliers, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,51 @@
+"""FrameProcessor::processFrame restated on top of the CPU oracle
+(reference src/frame_processor.cpp:18-202).  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import oracle as O
+
+
+class OracleStream:
+    """One camera stream: keeps the previous features and track ages."""
+
+    def __init__(self, camera=None, max_features=1000, fast_threshold=20, ratio=0.7,
+                 pnp_iters=100, pnp_threshold=8.0, pnp_confidence=0.99):
+        self.camera = camera  # (fx, fy, cx, cy) or None
+        self.max_features = max_features
+        self.fast_threshold = fast_threshold
+        self.ratio = ratio
+        self.pnp = (pnp_iters, pnp_threshold, pnp_confidence)
+        self.prev = None
+        self.prev_ages = np.zeros(0, np.int32)
+
+    def process(self, frame: np.ndarray, depth: np.ndarray | None = None) -> dict:
+        gray = frame if frame.ndim == 2 else O.gray(frame)
+        kps, desc = O.detect(gray, self.max_features, self.fast_threshold)
+        out = {"kps": kps, "desc": desc, "matches": np.zeros(0, O.MATCH_DTYPE), "n_ratio": 0,
+               "tracked": np.zeros(0, O.MATCH_DTYPE), "valid": np.zeros(0, O.MATCH_DTYPE),
+               "pts3": np.zeros((0, 3), np.float32), "pnp_success": False, "rvec": np.zeros(3),
+               "tvec": np.zeros(3), "inliers": np.zeros(0, np.int32)}
+        if self.prev is not None:
+            pk, pd = self.prev
+            if len(pk) and len(kps):
+                knn = O.knn2(pd, desc)
+                m, _, nr = O.match_filter(knn, len(kps), pk, kps, self.ratio)
+                out["matches"], out["n_ratio"] = m, nr
+            tracked, ages = O.track_filter(out["matches"], self.prev_ages, len(kps))
+            out["tracked"] = tracked
+            self.prev_ages = ages
+            if self.camera is not None and depth is not None and len(tracked):
+                fx, fy, cx, cy = self.camera
+                valid, pts3 = O.backproject(tracked, depth, fx, fy, cx, cy)
+                if len(pts3):
+                    out["valid"], out["pts3"] = valid, pts3
+                    if len(pts3) >= 4:
+                        img = np.stack([valid["px"], valid["py"]], 1)
+                        ok, rvec, tvec, inl = O.solve_pnp_ransac(pts3, img, fx, fy, cx, cy, *self.pnp)
+                        out.update(pnp_success=ok, rvec=rvec, tvec=tvec, inliers=inl)
+        else:
+            self.prev_ages = np.zeros(len(kps), np.int32)
+        self.prev = (kps, desc)
+        return out

@@ -1,5 +1,9 @@
-/* CPU oracle, pose from 3-D/2-D correspondences.  TEST INFRASTRUCTURE ONLY --
- * see vo_oracle.h.  PARITY UNPINNED (no OpenCV here, no reference vectors).
+/* CPU oracle, pose from 3-D/2-D correspondences: EPnP minimal solver,
+ * iterative (DLT + Levenberg-Marquardt) refinement and the RANSAC driver of
+ * cv::solvePnPRansac.  TEST INFRASTRUCTURE ONLY -- see vo_oracle.h.
+ * PARITY UNPINNED (no OpenCV here, no reference vectors); OpenCV's SVD-based
+ * linear algebra is replaced by Jacobi eigen/SVD and QR least squares, which
+ * agree with it up to rounding on well-conditioned input.
  */
 #include "vo_oracle.h"
 
@@ -8,23 +12,481 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* [OCV-recall] cv::Rodrigues, vector -> matrix */
-void ora_rodrigues_vec2mat(const double *r, double *R)
+static inline int ora_cv_round(double v) { return (int)lrint(v); }
+
+/* ------------------------------------------------------------ Rodrigues */
+
+/* [OCV-recall] cv::Rodrigues, vector -> matrix; J (optional) is the 3x9
+ * derivative dR(row-major)/dr laid out as OpenCV's jacobian. */
+static void rodrigues_v2m(const double *r, double *R, double *J)
 {
     double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
     if (theta < DBL_EPSILON) {
         for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        if (J) {
+            memset(J, 0, sizeof(double) * 27);
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
+        }
         return;
     }
     double c = cos(theta), s = sin(theta), c1 = 1. - c;
     double itheta = 1. / theta;
-    double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
-    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
-    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+    double n[3] = {r[0] * itheta, r[1] * itheta, r[2] * itheta};
+    double rrt[9] = {n[0] * n[0], n[0] * n[1], n[0] * n[2], n[0] * n[1], n[1] * n[1],
+                     n[1] * n[2], n[0] * n[2], n[1] * n[2], n[2] * n[2]};
+    double r_x[9] = {0, -n[2], n[1], n[2], 0, -n[0], -n[1], n[0], 0};
+    static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    if (J) {
+        double drrt[27] = {n[0] + n[0], n[1], n[2], n[1], 0, 0, n[2], 0, 0,
+                           0, n[0], 0, n[0], n[1] + n[1], n[2], 0, n[2], 0,
+                           0, 0, n[0], 0, 0, n[1], n[0], n[1], n[2] + n[2]};
+        static const double d_r_x[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                         0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                         0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            double ri = n[i];
+            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] +
+                               a4 * d_r_x[i * 9 + k];
+        }
+    }
 }
 
-/* [OCV-recall] cv::Rodrigues, matrix -> vector (input assumed orthonormal) */
+void ora_rodrigues_vec2mat(const double *r, double *R) { rodrigues_v2m(r, R, 0); }
+
+/* ------------------------------------------------- small dense algebra */
+
+/* cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 12).
+ * On return w holds eigenvalues in descending order and row i of Vt the
+ * matching unit eigenvector (the layout cvSVD(..., U_T) gives for a symmetric
+ * positive semi-definite input). */
+static void jacobi_eig_desc(const double *Ain, int n, double *w, double *Vt)
+{
+    double A[144], V[144];
+    memcpy(A, Ain, sizeof(double) * (size_t)(n * n));
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                if (i != j) off += A[i * n + j] * A[i * n + j];
+                else diag += A[i * n + j] * A[i * n + j];
+            }
+        if (off <= 1e-30 * diag || off == 0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int order[12];
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (A[order[j] * n + order[j]] > A[order[i] * n + order[i]]) {
+                int t = order[i]; order[i] = order[j]; order[j] = t;
+            }
+    for (int i = 0; i < n; i++) {
+        w[i] = A[order[i] * n + order[i]];
+        for (int k = 0; k < n; k++) Vt[i * n + k] = V[k * n + order[i]];
+    }
+}
+
+/* nearest rotation to a 3x3 matrix A (U V^T of its SVD), via the
+ * eigen-decomposition of A^T A; a vanishing third singular value is
+ * completed with a cross product. */
+static void polar_rotation3(const double *A, double *R)
+{
+    double AtA[9], w[3], Vt[9], U[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j];
+            AtA[i * 3 + j] = s;
+        }
+    jacobi_eig_desc(AtA, 3, w, Vt);
+    for (int c = 0; c < 3; c++) {
+        double u[3], nrm = 0;
+        for (int i = 0; i < 3; i++) {
+            u[i] = A[i * 3 + 0] * Vt[c * 3 + 0] + A[i * 3 + 1] * Vt[c * 3 + 1] + A[i * 3 + 2] * Vt[c * 3 + 2];
+            nrm += u[i] * u[i];
+        }
+        nrm = sqrt(nrm);
+        if (c == 2 && nrm <= 1e-12 * sqrt(w[0] > 0 ? w[0] : 1)) {
+            u[0] = U[3] * U[7] - U[6] * U[4];   /* u0 x u1, columns of U */
+            u[1] = U[6] * U[1] - U[0] * U[7];
+            u[2] = U[0] * U[4] - U[3] * U[1];
+            nrm = 1;
+        }
+        for (int i = 0; i < 3; i++) U[i * 3 + c] = u[i] / nrm;
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = U[i * 3 + 0] * Vt[0 * 3 + j] + U[i * 3 + 1] * Vt[1 * 3 + j] + U[i * 3 + 2] * Vt[2 * 3 + j];
+}
+
+/* least squares min |A x - b| for an m x n system (m >= n, n <= 6) by
+ * Householder QR */
+static void lstsq_qr(const double *Ain, const double *bin, int m, int n, double *x)
+{
+    double A[6 * 6 + 12], b[8];
+    memcpy(A, Ain, sizeof(double) * (size_t)(m * n));
+    memcpy(b, bin, sizeof(double) * (size_t)m);
+    for (int k = 0; k < n; k++) {
+        double s = 0;
+        for (int i = k; i < m; i++) s += A[i * n + k] * A[i * n + k];
+        double nrm = sqrt(s);
+        if (nrm == 0) continue;
+        double alpha = A[k * n + k] > 0 ? -nrm : nrm;
+        double v[8];
+        for (int i = k; i < m; i++) v[i] = A[i * n + k];
+        v[k] -= alpha;
+        double vn = 0;
+        for (int i = k; i < m; i++) vn += v[i] * v[i];
+        if (vn == 0) continue;
+        double beta = 2.0 / vn;
+        for (int j = k; j < n; j++) {
+            double dot = 0;
+            for (int i = k; i < m; i++) dot += v[i] * A[i * n + j];
+            dot *= beta;
+            for (int i = k; i < m; i++) A[i * n + j] -= dot * v[i];
+        }
+        double dot = 0;
+        for (int i = k; i < m; i++) dot += v[i] * b[i];
+        dot *= beta;
+        for (int i = k; i < m; i++) b[i] -= dot * v[i];
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double s = b[k];
+        for (int j = k + 1; j < n; j++) s -= A[k * n + j] * x[j];
+        x[k] = s / A[k * n + k];
+    }
+}
+
+/* solve the n x n system A x = b (n <= 6) by Gaussian elimination with
+ * partial pivoting; returns 0 when singular */
+static int solve_gauss(const double *Ain, const double *bin, int n, double *x)
+{
+    double A[36], b[6];
+    memcpy(A, Ain, sizeof(double) * (size_t)(n * n));
+    memcpy(b, bin, sizeof(double) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
+        if (A[piv * n + k] == 0) return 0;
+        if (piv != k) {
+            for (int j = 0; j < n; j++) { double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < n; i++) {
+            double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double s = b[k];
+        for (int j = k + 1; j < n; j++) s -= A[k * n + j] * x[j];
+        x[k] = s / A[k * n + k];
+    }
+    return 1;
+}
+
+static int invert3(const double *m, double *inv)
+{
+    double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+                 m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (det == 0) return 0;
+    double id = 1.0 / det;
+    inv[0] = (m[4] * m[8] - m[5] * m[7]) * id; inv[1] = (m[2] * m[7] - m[1] * m[8]) * id; inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = (m[5] * m[6] - m[3] * m[8]) * id; inv[4] = (m[0] * m[8] - m[2] * m[6]) * id; inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = (m[3] * m[7] - m[4] * m[6]) * id; inv[7] = (m[1] * m[6] - m[0] * m[7]) * id; inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return 1;
+}
+
+/* ----------------------------------------------------------------- EPnP */
+
+typedef struct {
+    int n;
+    double fu, fv, uc, vc;
+    const double *pws; /* n x 3 */
+    const double *us;  /* n x 2 (pixels) */
+    double *alphas;    /* n x 4 */
+    double *pcs;       /* n x 3 */
+    double cws[4][3], ccs[4][3];
+} epnp_t;
+
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double dist2(const double *a, const double *b)
+{
+    return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+}
+
+/* [OCV-recall] epnp::choose_control_points */
+static void epnp_control_points(epnp_t *e)
+{
+    int n = e->n;
+    e->cws[0][0] = e->cws[0][1] = e->cws[0][2] = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) e->cws[0][j] += e->pws[3 * i + j];
+    for (int j = 0; j < 3; j++) e->cws[0][j] /= n;
+    double ptp[9] = {0}, dc[3], uct[9];
+    for (int i = 0; i < n; i++) {
+        double d[3];
+        for (int j = 0; j < 3; j++) d[j] = e->pws[3 * i + j] - e->cws[0][j];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) ptp[a * 3 + b] += d[a] * d[b];
+    }
+    jacobi_eig_desc(ptp, 3, dc, uct);
+    for (int i = 1; i < 4; i++) {
+        double k = sqrt((dc[i - 1] > 0 ? dc[i - 1] : 0) / n);
+        for (int j = 0; j < 3; j++) e->cws[i][j] = e->cws[0][j] + k * uct[3 * (i - 1) + j];
+    }
+}
+
+/* [OCV-recall] epnp::compute_barycentric_coordinates */
+static int epnp_barycentric(epnp_t *e)
+{
+    double cc[9], ci[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e->cws[j][i] - e->cws[0][i];
+    if (!invert3(cc, ci)) return 0;
+    for (int i = 0; i < e->n; i++) {
+        const double *pi = e->pws + 3 * i;
+        double *a = e->alphas + 4 * i;
+        for (int j = 0; j < 3; j++)
+            a[1 + j] = ci[3 * j] * (pi[0] - e->cws[0][0]) + ci[3 * j + 1] * (pi[1] - e->cws[0][1]) +
+                       ci[3 * j + 2] * (pi[2] - e->cws[0][2]);
+        a[0] = 1.0 - a[1] - a[2] - a[3];
+    }
+    return 1;
+}
+
+static void epnp_compute_ccs_pcs(epnp_t *e, const double *betas, const double *ut)
+{
+    for (int i = 0; i < 4; i++) e->ccs[i][0] = e->ccs[i][1] = e->ccs[i][2] = 0;
+    for (int i = 0; i < 4; i++) {
+        const double *v = ut + 12 * (11 - i);
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) e->ccs[j][k] += betas[i] * v[3 * j + k];
+    }
+    for (int i = 0; i < e->n; i++) {
+        const double *a = e->alphas + 4 * i;
+        double *pc = e->pcs + 3 * i;
+        for (int j = 0; j < 3; j++)
+            pc[j] = a[0] * e->ccs[0][j] + a[1] * e->ccs[1][j] + a[2] * e->ccs[2][j] + a[3] * e->ccs[3][j];
+    }
+    if (e->pcs[2] < 0.0) { /* solve_for_sign */
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 3; j++) e->ccs[i][j] = -e->ccs[i][j];
+        for (int i = 0; i < 3 * e->n; i++) e->pcs[i] = -e->pcs[i];
+    }
+}
+
+/* [OCV-recall] epnp::estimate_R_and_t + reprojection_error */
+static double epnp_R_and_t(epnp_t *e, const double *ut, const double *betas, double R[9], double t[3])
+{
+    int n = e->n;
+    epnp_compute_ccs_pcs(e, betas, ut);
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) { pc0[j] += e->pcs[3 * i + j]; pw0[j] += e->pws[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0};
+    for (int i = 0; i < n; i++) {
+        const double *pc = e->pcs + 3 * i, *pw = e->pws + 3 * i;
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    polar_rotation3(abt, R);
+    double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] -
+                 R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
+    if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+    t[0] = pc0[0] - dot3(R, pw0);
+    t[1] = pc0[1] - dot3(R + 3, pw0);
+    t[2] = pc0[2] - dot3(R + 6, pw0);
+    double sum2 = 0;
+    for (int i = 0; i < n; i++) {
+        const double *pw = e->pws + 3 * i;
+        double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1];
+        double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+        double ue = e->uc + e->fu * Xc * inv_Zc, ve = e->vc + e->fv * Yc * inv_Zc;
+        double u = e->us[2 * i], v = e->us[2 * i + 1];
+        sum2 += sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return sum2 / n;
+}
+
+/* [OCV-recall] epnp::gauss_newton (5 iterations, 6x4 least squares) */
+static void epnp_gauss_newton(const double *L, const double *rho, double betas[4])
+{
+    for (int k = 0; k < 5; k++) {
+        double A[24], b[6], x[4];
+        for (int i = 0; i < 6; i++) {
+            const double *rowL = L + i * 10;
+            double *rowA = A + i * 4;
+            rowA[0] = 2 * rowL[0] * betas[0] + rowL[1] * betas[1] + rowL[3] * betas[2] + rowL[6] * betas[3];
+            rowA[1] = rowL[1] * betas[0] + 2 * rowL[2] * betas[1] + rowL[4] * betas[2] + rowL[7] * betas[3];
+            rowA[2] = rowL[3] * betas[0] + rowL[4] * betas[1] + 2 * rowL[5] * betas[2] + rowL[8] * betas[3];
+            rowA[3] = rowL[6] * betas[0] + rowL[7] * betas[1] + rowL[8] * betas[2] + 2 * rowL[9] * betas[3];
+            b[i] = rho[i] - (rowL[0] * betas[0] * betas[0] + rowL[1] * betas[0] * betas[1] +
+                             rowL[2] * betas[1] * betas[1] + rowL[3] * betas[0] * betas[2] +
+                             rowL[4] * betas[1] * betas[2] + rowL[5] * betas[2] * betas[2] +
+                             rowL[6] * betas[0] * betas[3] + rowL[7] * betas[1] * betas[3] +
+                             rowL[8] * betas[2] * betas[3] + rowL[9] * betas[3] * betas[3]);
+        }
+        lstsq_qr(A, b, 6, 4, x);
+        for (int i = 0; i < 4; i++) betas[i] += x[i];
+    }
+}
+
+/* [OCV-recall] epnp::compute_pose.  obj: n x 3, img: n x 2 in pixels. */
+static int epnp_solve(const double *obj, const double *img, int n, double fu, double fv, double uc,
+                      double vc, double R[9], double t[3])
+{
+    epnp_t e;
+    e.n = n; e.fu = fu; e.fv = fv; e.uc = uc; e.vc = vc; e.pws = obj; e.us = img;
+    e.alphas = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+    e.pcs = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+    int ok = 0;
+    epnp_control_points(&e);
+    if (epnp_barycentric(&e)) {
+        double mtm[144] = {0}, d[12], ut[144];
+        for (int i = 0; i < n; i++) {
+            const double *as = e.alphas + 4 * i;
+            double m1[12], m2[12];
+            for (int k = 0; k < 4; k++) {
+                m1[3 * k] = as[k] * fu; m1[3 * k + 1] = 0.0; m1[3 * k + 2] = as[k] * (uc - img[2 * i]);
+                m2[3 * k] = 0.0; m2[3 * k + 1] = as[k] * fv; m2[3 * k + 2] = as[k] * (vc - img[2 * i + 1]);
+            }
+            for (int a = 0; a < 12; a++)
+                for (int b = 0; b < 12; b++) mtm[a * 12 + b] += m1[a] * m1[b] + m2[a] * m2[b];
+        }
+        jacobi_eig_desc(mtm, 12, d, ut);
+
+        /* compute_L_6x10 / compute_rho */
+        double L[60], rho[6];
+        const double *v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
+        double dv[4][6][3];
+        for (int i = 0; i < 4; i++) {
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
+                dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
+                dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+        for (int i = 0; i < 6; i++) {
+            double *row = L + 10 * i;
+            row[0] = dot3(dv[0][i], dv[0][i]);
+            row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+            row[2] = dot3(dv[1][i], dv[1][i]);
+            row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+            row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+            row[5] = dot3(dv[2][i], dv[2][i]);
+            row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+            row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+            row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+            row[9] = dot3(dv[3][i], dv[3][i]);
+        }
+        rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]);
+        rho[2] = dist2(e.cws[0], e.cws[3]); rho[3] = dist2(e.cws[1], e.cws[2]);
+        rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
+
+        double Betas[4][4] = {{0}}, rep[4] = {0}, Rs[4][9], ts[4][3];
+        /* approx 1: [B11 B12 B13 B14] */
+        {
+            double l[24], b4[4];
+            for (int i = 0; i < 6; i++) {
+                l[i * 4] = L[i * 10]; l[i * 4 + 1] = L[i * 10 + 1];
+                l[i * 4 + 2] = L[i * 10 + 3]; l[i * 4 + 3] = L[i * 10 + 6];
+            }
+            lstsq_qr(l, rho, 6, 4, b4);
+            double *be = Betas[1];
+            if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
+            else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
+        }
+        epnp_gauss_newton(L, rho, Betas[1]);
+        rep[1] = epnp_R_and_t(&e, ut, Betas[1], Rs[1], ts[1]);
+        /* approx 2: [B11 B12 B22] */
+        {
+            double l[18], b3[3];
+            for (int i = 0; i < 6; i++) { l[i * 3] = L[i * 10]; l[i * 3 + 1] = L[i * 10 + 1]; l[i * 3 + 2] = L[i * 10 + 2]; }
+            lstsq_qr(l, rho, 6, 3, b3);
+            double *be = Betas[2];
+            if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
+            else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
+            if (b3[1] < 0) be[0] = -be[0];
+            be[2] = 0.0; be[3] = 0.0;
+        }
+        epnp_gauss_newton(L, rho, Betas[2]);
+        rep[2] = epnp_R_and_t(&e, ut, Betas[2], Rs[2], ts[2]);
+        /* approx 3: [B11 B12 B22 B13 B23] */
+        {
+            double l[30], b5[5];
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 5; j++) l[i * 5 + j] = L[i * 10 + j];
+            lstsq_qr(l, rho, 6, 5, b5);
+            double *be = Betas[3];
+            if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+            else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+            if (b5[1] < 0) be[0] = -be[0];
+            be[2] = b5[3] / be[0];
+            be[3] = 0.0;
+        }
+        epnp_gauss_newton(L, rho, Betas[3]);
+        rep[3] = epnp_R_and_t(&e, ut, Betas[3], Rs[3], ts[3]);
+
+        int N = 1;
+        if (rep[2] < rep[1]) N = 2;
+        if (rep[3] < rep[N]) N = 3;
+        memcpy(R, Rs[N], sizeof(double) * 9);
+        memcpy(t, ts[N], sizeof(double) * 3);
+        ok = 1;
+        for (int i = 0; i < 9; i++) if (!isfinite(R[i])) ok = 0;
+        for (int i = 0; i < 3; i++) if (!isfinite(t[i])) ok = 0;
+    }
+    free(e.alphas); free(e.pcs);
+    return ok;
+}
+
+int ora_epnp(const double *obj, const double *img_px, int n, double *R, double *t)
+{
+    /* img_px are pixels of a camera with fu = fv = 1, uc = vc = 0 (normalised) */
+    return epnp_solve(obj, img_px, n, 1.0, 1.0, 0.0, 0.0, R, t);
+}
+
+/* [OCV-recall] cv::Rodrigues, matrix -> vector.  OpenCV first projects the
+ * input on SO(3) (SVD); the solvers here only pass rotations. */
 void ora_rodrigues_mat2vec(const double *R, double *r)
 {
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
@@ -48,29 +510,274 @@ void ora_rodrigues_mat2vec(const double *R, double *r)
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
-/* The PnP solvers are filled in below (EPnP minimal solver, iterative
- * refinement, RANSAC driver). */
-int ora_epnp(const double *obj, const double *img_norm, int n, double *R, double *t)
+/* ---------------------------------------------- iterative refinement */
+
+/* residuals (proj - measured) and optionally the 2n x 6 Jacobian w.r.t.
+ * (rvec, tvec); [OCV-recall] cvProjectPoints2 without distortion */
+static void project_residuals(const double *obj, const double *img, int n, double fx, double fy,
+                              double cx, double cy, const double *param, double *err, double *J)
 {
-    (void)obj; (void)img_norm; (void)n; (void)R; (void)t;
-    return 0;
+    double R[9], dRdr[27];
+    rodrigues_v2m(param, R, J ? dRdr : 0);
+    const double *t = param + 3;
+    for (int i = 0; i < n; i++) {
+        const double *M = obj + 3 * i;
+        double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+        double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+        double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+        double z = Z ? 1. / Z : 1;
+        double x = X * z, y = Y * z;
+        err[2 * i] = x * fx + cx - img[2 * i];
+        err[2 * i + 1] = y * fy + cy - img[2 * i + 1];
+        if (J) {
+            double *j0 = J + (size_t)(2 * i) * 6, *j1 = j0 + 6;
+            /* d/dt */
+            j0[3] = fx * z; j0[4] = 0; j0[5] = -fx * x * z;
+            j1[3] = 0; j1[4] = fy * z; j1[5] = -fy * y * z;
+            /* d/dr: dX/dr_k = dR/dr_k * M */
+            for (int k = 0; k < 3; k++) {
+                const double *d = dRdr + 9 * k;
+                double dX = d[0] * M[0] + d[1] * M[1] + d[2] * M[2];
+                double dY = d[3] * M[0] + d[4] * M[1] + d[5] * M[2];
+                double dZ = d[6] * M[0] + d[7] * M[1] + d[8] * M[2];
+                j0[k] = fx * (dX - x * dZ) * z;
+                j1[k] = fy * (dY - y * dZ) * z;
+            }
+        }
+    }
 }
 
-int ora_pnp_iterative(const double *obj, const double *img, int n, double fx,
-                      double fy, double cx, double cy, double *rvec, double *tvec)
+/* [OCV-recall] cvFindExtrinsicCameraParams2 without extrinsic guess:
+ * DLT initialisation (non-planar, >= 6 points) + CvLevMarq (<= 20 iterations,
+ * eps FLT_EPSILON).  obj n x 3, img n x 2 pixels. Returns 0 when the DLT
+ * preconditions fail (planar or fewer than 6 points -- not restated). */
+int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, double fy, double cx,
+                      double cy, double *rvec, double *tvec)
 {
-    (void)obj; (void)img; (void)n; (void)fx; (void)fy; (void)cx; (void)cy;
-    (void)rvec; (void)tvec;
-    return 0;
+    if (n < 6) return 0;
+    /* planarity test on the object points */
+    double Mc[3] = {0, 0, 0}, MM[9] = {0}, W[3], Vt[9];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) Mc[j] += obj[3 * i + j];
+    for (int j = 0; j < 3; j++) Mc[j] /= n;
+    for (int i = 0; i < n; i++) {
+        double d[3] = {obj[3 * i] - Mc[0], obj[3 * i + 1] - Mc[1], obj[3 * i + 2] - Mc[2]};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) MM[a * 3 + b] += d[a] * d[b];
+    }
+    jacobi_eig_desc(MM, 3, W, Vt);
+    if (W[2] / W[1] < 1e-3) return 0;
+
+    /* DLT on normalised image points */
+    double LL[144] = {0}, LW[12], LV[144];
+    for (int i = 0; i < n; i++) {
+        const double *M = obj + 3 * i;
+        double x = -(img[2 * i] - cx) / fx, y = -(img[2 * i + 1] - cy) / fy;
+        double r0[12] = {M[0], M[1], M[2], 1, 0, 0, 0, 0, x * M[0], x * M[1], x * M[2], x};
+        double r1[12] = {0, 0, 0, 0, M[0], M[1], M[2], 1, y * M[0], y * M[1], y * M[2], y};
+        for (int a = 0; a < 12; a++)
+            for (int b = 0; b < 12; b++) LL[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
+    }
+    jacobi_eig_desc(LL, 12, LW, LV);
+    double RRt[12];
+    memcpy(RRt, LV + 11 * 12, sizeof(RRt));
+    double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
+    double tt[3] = {RRt[3], RRt[7], RRt[11]};
+    double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +
+                 RR[2] * (RR[3] * RR[7] - RR[4] * RR[6]);
+    if (det < 0) {
+        for (int i = 0; i < 9; i++) RR[i] = -RR[i];
+        for (int i = 0; i < 3; i++) tt[i] = -tt[i];
+    }
+    double sc = 0;
+    for (int i = 0; i < 9; i++) sc += RR[i] * RR[i];
+    sc = sqrt(sc);
+    if (fabs(sc) <= DBL_EPSILON) return 0;
+    double R[9];
+    polar_rotation3(RR, R);
+    double nR = 0;
+    for (int i = 0; i < 9; i++) nR += R[i] * R[i];
+    nR = sqrt(nR);
+    double param[6], prev[6];
+    ora_rodrigues_mat2vec(R, param);
+    for (int i = 0; i < 3; i++) param[3 + i] = tt[i] * nR / sc;
+
+    /* CvLevMarq */
+    const int max_iter = 20;
+    const double eps = FLT_EPSILON;
+    double *err = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *J = (double *)malloc(sizeof(double) * 12 * (size_t)n);
+    double JtJ[36], JtErr[6];
+    double prevErrNorm = DBL_MAX, errNorm = 0;
+    int lambdaLg10 = -3, iters = 0;
+    const double LOG10 = log(10.);
+    for (;;) {
+        /* CALC_J */
+        project_residuals(obj, img, n, fx, fy, cx, cy, param, err, J);
+        memset(JtJ, 0, sizeof(JtJ));
+        memset(JtErr, 0, sizeof(JtErr));
+        double e2 = 0;
+        for (int i = 0; i < 2 * n; i++) {
+            const double *j = J + (size_t)i * 6;
+            for (int a = 0; a < 6; a++) {
+                JtErr[a] += j[a] * err[i];
+                for (int b = 0; b < 6; b++) JtJ[a * 6 + b] += j[a] * j[b];
+            }
+            e2 += err[i] * err[i];
+        }
+        memcpy(prev, param, sizeof(prev));
+        if (iters == 0) prevErrNorm = sqrt(e2);
+        int accepted = 0;
+        for (;;) {
+            /* step() */
+            double lambda = exp(lambdaLg10 * LOG10);
+            double A[36], dx[6];
+            memcpy(A, JtJ, sizeof(A));
+            for (int a = 0; a < 6; a++) A[a * 6 + a] *= 1. + lambda;
+            if (!solve_gauss(A, JtErr, 6, dx)) memset(dx, 0, sizeof(dx));
+            for (int a = 0; a < 6; a++) param[a] = prev[a] - dx[a];
+            /* CHECK_ERR */
+            project_residuals(obj, img, n, fx, fy, cx, cy, param, err, 0);
+            e2 = 0;
+            for (int i = 0; i < 2 * n; i++) e2 += err[i] * err[i];
+            errNorm = sqrt(e2);
+            if (errNorm > prevErrNorm) {
+                if (++lambdaLg10 <= 16) continue;
+            }
+            accepted = 1;
+            break;
+        }
+        (void)accepted;
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        double dn = 0, pn = 0;
+        for (int a = 0; a < 6; a++) { dn += (param[a] - prev[a]) * (param[a] - prev[a]); pn += prev[a] * prev[a]; }
+        if (++iters >= max_iter || sqrt(dn) / sqrt(pn) < eps) break;
+        prevErrNorm = errNorm;
+    }
+    free(err); free(J);
+    memcpy(rvec, param, sizeof(double) * 3);
+    memcpy(tvec, param + 3, sizeof(double) * 3);
+    return 1;
 }
 
-int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx,
-                         double fy, double cx, double cy, int iters,
-                         double thr, double conf, double *rvec, double *tvec,
+/* ------------------------------------------------------- RANSAC driver */
+
+/* [OCV-recall] RANSACUpdateNumIters */
+static int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : (p > 1 ? 1 : p);
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : ora_cv_round(num / denom);
+}
+
+/* [OCV-recall] PnPRansacCallback::computeError: projectPoints in double,
+ * stored as float, squared pixel distance */
+static void pnp_errors(const float *obj, const float *img, int n, double fx, double fy, double cx,
+                       double cy, const double *rvec, const double *tvec, float *err)
+{
+    double R[9];
+    rodrigues_v2m(rvec, R, 0);
+    for (int i = 0; i < n; i++) {
+        double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + tvec[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + tvec[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + tvec[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        float px = (float)(x * fx + cx), py = (float)(y * fy + cy);
+        float dx = img[2 * i] - px, dy = img[2 * i + 1] - py;
+        err[i] = (float)((double)dx * dx + (double)dy * dy);
+    }
+}
+
+/* [OCV-recall] cv::solvePnPRansac, EPnP on 5-point samples (n > 5), final
+ * iterative refinement on the inliers.  With n == 5 OpenCV runs the minimal
+ * solver once; n == 4 (P3P) is not restated and reports failure. */
+int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx, double fy, double cx,
+                         double cy, int iters, double thr, double conf, double *rvec, double *tvec,
                          int32_t *inliers, int *n_inliers)
 {
-    (void)obj; (void)img; (void)n; (void)fx; (void)fy; (void)cx; (void)cy;
-    (void)iters; (void)thr; (void)conf; (void)rvec; (void)tvec; (void)inliers;
+    const int model_points = 5;
     if (n_inliers) *n_inliers = 0;
-    return 0;
+    for (int i = 0; i < 3; i++) rvec[i] = tvec[i] = 0;
+    if (n < model_points) return 0;
+
+    double so[15], si[10], R[9], t[3];
+    if (n == model_points) {
+        for (int i = 0; i < 5; i++) {
+            for (int j = 0; j < 3; j++) so[3 * i + j] = obj[3 * i + j];
+            si[2 * i] = img[2 * i]; si[2 * i + 1] = img[2 * i + 1];
+        }
+        if (!epnp_solve(so, si, 5, fx, fy, cx, cy, R, t)) return 0;
+        ora_rodrigues_mat2vec(R, rvec);
+        memcpy(tvec, t, sizeof(t));
+        for (int i = 0; i < n; i++) inliers[i] = i;
+        *n_inliers = n;
+        return 1;
+    }
+
+    ora_rng rng = {(uint64_t)-1};
+    int niters = iters > 1 ? iters : 1, max_good = 0;
+    float *err = (float *)malloc(sizeof(float) * (size_t)n);
+    uint8_t *mask = (uint8_t *)calloc((size_t)n, 1), *cur = (uint8_t *)malloc((size_t)n);
+    double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
+    const float tt = (float)(thr * thr);
+    for (int iter = 0; iter < niters; iter++) {
+        int idx[5];
+        for (int i = 0; i < model_points; i++) {
+            int v;
+            for (;;) {
+                v = ora_rng_uniform(&rng, 0, n);
+                int dup = 0;
+                for (int j = 0; j < i; j++) if (idx[j] == v) { dup = 1; break; }
+                if (!dup) break;
+            }
+            idx[i] = v;
+            for (int j = 0; j < 3; j++) so[3 * i + j] = obj[3 * v + j];
+            si[2 * i] = img[2 * v]; si[2 * i + 1] = img[2 * v + 1];
+        }
+        if (!epnp_solve(so, si, 5, fx, fy, cx, cy, R, t)) continue;
+        double rv[3];
+        ora_rodrigues_mat2vec(R, rv);
+        pnp_errors(obj, img, n, fx, fy, cx, cy, rv, t, err);
+        int good = 0;
+        for (int i = 0; i < n; i++) { cur[i] = (uint8_t)(err[i] <= tt); good += cur[i]; }
+        if (good > (max_good > model_points - 1 ? max_good : model_points - 1)) {
+            memcpy(mask, cur, (size_t)n);
+            memcpy(best_r, rv, sizeof(rv));
+            memcpy(best_t, t, sizeof(t));
+            max_good = good;
+            niters = ransac_update_num_iters(conf, (double)(n - good) / n, model_points, niters);
+        }
+    }
+    int ok = 0;
+    if (max_good > 0) {
+        /* refine on the inliers */
+        double *io = (double *)malloc(sizeof(double) * 3 * (size_t)max_good);
+        double *ii = (double *)malloc(sizeof(double) * 2 * (size_t)max_good);
+        int k = 0;
+        for (int i = 0; i < n; i++)
+            if (mask[i]) {
+                for (int j = 0; j < 3; j++) io[3 * k + j] = obj[3 * i + j];
+                ii[2 * k] = img[2 * i]; ii[2 * k + 1] = img[2 * i + 1];
+                k++;
+            }
+        if (ora_pnp_iterative(io, ii, k, fx, fy, cx, cy, rvec, tvec)) {
+            ok = 1;
+            k = 0;
+            for (int i = 0; i < n; i++) if (mask[i]) inliers[k++] = i;
+            *n_inliers = k;
+        } else {
+            memcpy(rvec, best_r, sizeof(best_r));
+            memcpy(tvec, best_t, sizeof(best_t));
+        }
+        free(io); free(ii);
+    }
+    free(err); free(mask); free(cur);
+    return ok;
 }

@@ -32,6 +32,23 @@ class VoCfg(C.Structure):
                 ("gray_r", C.c_int), ("gray_shift", C.c_int)]
 
 
+class VoBatchCfg(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("channels", C.c_int),
+                ("n_streams", C.c_int), ("frames_per_stream", C.c_int),
+                ("max_features", C.c_int), ("fast_threshold", C.c_int), ("ratio", C.c_float),
+                ("f_threshold", C.c_double), ("f_confidence", C.c_double), ("f_max_iters", C.c_int),
+                ("enable_pose", C.c_int), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("pnp_iters", C.c_int), ("pnp_threshold", C.c_double),
+                ("pnp_confidence", C.c_double)]
+
+
+RESULT_DTYPE = np.dtype([("n_keypoints", "<i4"), ("n_ratio", "<i4"), ("f_found", "<i4"),
+                         ("f_iters", "<i4"), ("f_inliers", "<i4"), ("n_matches", "<i4"),
+                         ("n_tracked", "<i4"), ("n_3d", "<i4"), ("pnp_success", "<i4"),
+                         ("pnp_inliers", "<i4"), ("pnp_iters", "<i4"), ("pnp_points", "<i4"),
+                         ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,))])
+
+
 class VoError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libvo_hip error {code}: {msg}")
@@ -53,6 +70,15 @@ EXPORTS = {
     "vo_find_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                              _P, _P, _P, _P]),
     "vo_match_features": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P]),
+    "vo_solve_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
+    "vo_batch_configure": (C.c_int, [_P, C.POINTER(VoBatchCfg)]),
+    "vo_batch_reset": (C.c_int, [_P]),
+    "vo_batch_submit": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _P, C.c_int, C.c_size_t]),
+    "vo_batch_wait": (C.c_int, [_P, _P]),
+    "vo_batch_get_features": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "vo_batch_get_matches": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    "vo_batch_get_inliers": (C.c_int, [_P, C.c_int, _P, _P]),
 }
 
 _lib = None
@@ -171,4 +197,83 @@ class Context:
         self._check(self._lib.vo_match_features(self._h, _ptr(prev_kps), _ptr(prev_desc), len(prev_kps),
                                                 _ptr(curr_kps), _ptr(curr_desc), len(curr_kps), ratio,
                                                 _ptr(out), C.addressof(n)))
+        return out[:n.value].copy()
+
+    def solve_pnp_ransac(self, obj, img, fx, fy, cx, cy, iters=100, thr=8.0, conf=0.99):
+        obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+        img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+        n = len(obj)
+        rvec = np.zeros(3)
+        tvec = np.zeros(3)
+        inl = np.zeros(max(n, 1), np.int32)
+        ninl = C.c_int(0)
+        ok = C.c_int(0)
+        self._check(self._lib.vo_solve_pnp_ransac(self._h, _ptr(obj), _ptr(img), n, fx, fy, cx, cy, iters,
+                                                  thr, conf, _ptr(rvec), _ptr(tvec), _ptr(inl),
+                                                  C.addressof(ninl), C.addressof(ok)))
+        return bool(ok.value), rvec, tvec, inl[:ninl.value].copy()
+
+    # ---- batched pipeline ---------------------------------------------
+    def batch_configure(self, width, height, channels, n_streams=1, frames_per_stream=1,
+                        max_features=1000, fast_threshold=20, ratio=0.7, f_threshold=3.0,
+                        f_confidence=0.99, f_max_iters=1000, camera=None, pnp_iters=100,
+                        pnp_threshold=8.0, pnp_confidence=0.99):
+        """camera: (fx, fy, cx, cy) enables depth back-projection + PnP."""
+        fx, fy, cx, cy = camera if camera is not None else (0.0, 0.0, 0.0, 0.0)
+        cfg = VoBatchCfg(width, height, channels, n_streams, frames_per_stream, max_features,
+                         fast_threshold, ratio, f_threshold, f_confidence, f_max_iters,
+                         1 if camera is not None else 0, fx, fy, cx, cy, pnp_iters, pnp_threshold,
+                         pnp_confidence)
+        self._check(self._lib.vo_batch_configure(self._h, C.byref(cfg)))
+        self._bcfg = cfg
+        self._batch = n_streams * frames_per_stream
+
+    def batch_reset(self):
+        self._check(self._lib.vo_batch_reset(self._h))
+
+    def batch_submit_ptr(self, frames_ptr, row_stride, frame_stride, depth_ptr=None, depth_row_stride=0,
+                         depth_frame_stride=0):
+        """Raw pointers (ints), e.g. device memory owned by the caller."""
+        self._check(self._lib.vo_batch_submit(self._h, frames_ptr, row_stride, frame_stride, depth_ptr,
+                                              depth_row_stride, depth_frame_stride))
+
+    def batch_submit(self, frames: np.ndarray, depth: np.ndarray | None = None):
+        """frames: (batch, H, W[, C]) uint8 host array; depth: (batch, H, W) float32."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        cfg = self._bcfg
+        assert frames.shape[0] == self._batch and frames.shape[1] == cfg.height and frames.shape[2] == cfg.width
+        row = cfg.width * cfg.channels
+        self._keep = [frames]
+        dptr, drow, dfr = None, 0, 0
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.float32)
+            self._keep.append(depth)
+            dptr, drow, dfr = _ptr(depth), cfg.width, cfg.width * cfg.height
+        self._check(self._lib.vo_batch_submit(self._h, _ptr(frames), row, row * cfg.height, dptr, drow, dfr))
+
+    def batch_wait(self) -> np.ndarray:
+        res = np.zeros(self._batch, RESULT_DTYPE)
+        self._check(self._lib.vo_batch_wait(self._h, _ptr(res)))
+        self._keep = None
+        return res
+
+    def batch_features(self, frame: int):
+        kps = np.zeros(self.max_features, KP_DTYPE)
+        desc = np.zeros((self.max_features, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self._lib.vo_batch_get_features(self._h, frame, _ptr(kps), _ptr(desc), C.addressof(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def batch_matches(self, frame: int, which: int = 0):
+        out = np.zeros(self.max_features, MATCH_DTYPE)
+        pts3 = np.zeros((self.max_features, 3), np.float32)
+        n = C.c_int(0)
+        self._check(self._lib.vo_batch_get_matches(self._h, frame, which, _ptr(out), _ptr(pts3),
+                                                   C.addressof(n)))
+        return out[:n.value].copy(), pts3[:n.value].copy()
+
+    def batch_inliers(self, frame: int):
+        out = np.zeros(self.max_features, np.int32)
+        n = C.c_int(0)
+        self._check(self._lib.vo_batch_get_inliers(self._h, frame, _ptr(out), C.addressof(n)))
         return out[:n.value].copy()

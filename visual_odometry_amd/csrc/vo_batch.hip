@@ -1,0 +1,274 @@
+// C ABI, part 2: cv::solvePnPRansac operator and the batched pipeline
+// (FrameProcessor::processFrame for many frames / streams per call).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "vo_ctx.h"
+
+using namespace vo;
+
+static int bfail(vo_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return bfail(ctx, VO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                     \
+    } while (0)
+
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+extern "C" {
+
+int vo_solve_pnp_ransac(vo_ctx *c, const float *obj, const float *img, int n, double fx, double fy, double cx,
+                        double cy, int iters, double thr, double conf, double *rvec, double *tvec,
+                        int32_t *inliers, int *n_inliers, int *success)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!obj || !img || !rvec || !tvec || n < 0 || n > c->cfg.max_features)
+        return bfail(c, VO_ERR_ARG, "vo_solve_pnp_ransac: bad arguments (n %d, limit %d)", n,
+                     c->cfg.max_features);
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<float> o(3 * (size_t)n + 1), im(2 * (size_t)n + 1);
+    if (n) {
+        HIP_TRY(c, hipMemcpy(o.data(), obj, sizeof(float) * 3 * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(im.data(), img, sizeof(float) * 2 * n, hipMemcpyDefault));
+    }
+    std::vector<vo_match> vm((size_t)n + 1);
+    for (int i = 0; i < n; i++) {
+        vm[i].query = vm[i].train = i; vm[i].distance = 0;
+        vm[i].px = im[2 * i]; vm[i].py = im[2 * i + 1];
+        vm[i].cx = vm[i].cy = 0;
+    }
+    const int bp[2] = {n, n};
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->d_valid, vm.data(), sizeof(vo_match) * n, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_pts3, o.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, hipMemcpy(c->d_bpinfo, bp, sizeof(bp), hipMemcpyHostToDevice));
+    launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, fx, fy, cx, cy,
+                      iters, thr, conf, c->d_inliers, c->d_pose, c->d_rt, 1, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_solve_pnp_ransac: %s", hipGetErrorString(e));
+    int pose[4];
+    double rt[6];
+    HIP_TRY(c, hipMemcpy(pose, c->d_pose, sizeof(pose), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(rt, c->d_rt, sizeof(rt), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; i++) { rvec[i] = rt[i]; tvec[i] = rt[3 + i]; }
+    if (success) *success = pose[0];
+    if (n_inliers) *n_inliers = pose[1];
+    if (inliers && pose[1] > 0)
+        HIP_TRY(c, hipMemcpy(inliers, c->d_inliers, sizeof(int) * pose[1], hipMemcpyDefault));
+    return VO_OK;
+}
+
+int vo_batch_configure(vo_ctx *c, const vo_batch_cfg *b)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!b || b->width < 7 || b->height < 7 || b->width > c->cfg.max_width || b->height > c->cfg.max_height ||
+        (b->channels != 1 && b->channels != 3 && b->channels != 4) || b->n_streams < 1 ||
+        b->frames_per_stream < 1 || (long long)b->n_streams * b->frames_per_stream > c->cfg.max_batch ||
+        b->max_features < 1 || b->max_features > c->cfg.max_features)
+        return bfail(c, VO_ERR_ARG, "vo_batch_configure: configuration outside the context limits");
+    if (b->enable_pose && !(b->fx > 0 && b->fy > 0))
+        return bfail(c, VO_ERR_ARG, "vo_batch_configure: pose needs fx, fy > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->bcfg = *b;
+    c->configured = true;
+    c->submitted = false;
+    return vo_batch_reset(c);
+}
+
+int vo_batch_reset(vo_ctx *c)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured) return bfail(c, VO_ERR_STATE, "vo_batch_reset: configure first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->streams_started = false;
+    c->first_pairs_linked = false;
+    const int S = c->bcfg.n_streams, F = c->bcfg.frames_per_stream, B = S * F;
+    std::vector<int> q(B), t(B), hp(B);
+    for (int s = 0; s < S; s++)
+        for (int f = 0; f < F; f++) {
+            const int b = s * F + f;
+            t[b] = S + b;  // slots 0..S-1 carry each stream's previous frame
+            hp[b] = f > 0;
+            q[b] = f > 0 ? t[b] - 1 : c->empty_slot;
+        }
+    HIP_TRY(c, hipMemcpy(c->d_qslot, q.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_tslot, t.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_has_prev, hp.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_nkp, 0, sizeof(int) * c->slots));
+    HIP_TRY(c, hipMemset(c->d_ages, 0, sizeof(int) * (size_t)c->kp_stride * c->slots));
+    HIP_TRY(c, hipMemset(c->d_pose, 0, sizeof(int) * 4 * B));
+    HIP_TRY(c, hipMemset(c->d_rt, 0, sizeof(double) * 6 * B));
+    HIP_TRY(c, hipMemset(c->d_bpinfo, 0, sizeof(int) * 2 * B));
+    return VO_OK;
+}
+
+int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride, const float *depth,
+                    int depth_row_stride, size_t depth_frame_stride)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured) return bfail(c, VO_ERR_STATE, "vo_batch_submit: configure first");
+    if (c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_submit: previous batch not waited for");
+    const vo_batch_cfg &b = c->bcfg;
+    const int S = b.n_streams, F = b.frames_per_stream, B = S * F;
+    const int row_bytes = b.width * b.channels;
+    if (!frames || row_stride < row_bytes || frame_stride < (size_t)row_stride * b.height)
+        return bfail(c, VO_ERR_ARG, "vo_batch_submit: bad frame strides");
+    if (depth && (depth_row_stride < b.width || depth_frame_stride < (size_t)depth_row_stride * b.height))
+        return bfail(c, VO_ERR_ARG, "vo_batch_submit: bad depth strides");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    if (c->streams_started && !c->first_pairs_linked) {
+        // from the second batch on, frame 0 of every stream pairs with the carry slot
+        std::vector<int> q(B), hp(B, 1);
+        for (int s = 0; s < S; s++)
+            for (int f = 0; f < F; f++) q[s * F + f] = f > 0 ? S + s * F + f - 1 : s;
+        HIP_TRY(c, hipMemcpyAsync(c->d_qslot, q.data(), sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_has_prev, hp.data(), sizeof(int) * B, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->first_pairs_linked = true;
+    }
+
+    const uint8_t *src = frames;
+    if (!is_device_ptr(frames)) {
+        for (int i = 0; i < B; i++)
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)i * row_bytes * b.height, row_bytes,
+                                        frames + i * frame_stride, row_stride, row_bytes, b.height,
+                                        hipMemcpyHostToDevice, c->stream));
+        src = c->d_in;
+        row_stride = row_bytes;
+        frame_stride = (size_t)row_bytes * b.height;
+    }
+    const float *dsrc = depth;
+    if (depth && b.enable_pose && !is_device_ptr(depth)) {
+        for (int i = 0; i < B; i++)
+            HIP_TRY(c, hipMemcpy2DAsync(c->d_depth + (size_t)i * b.width * b.height, sizeof(float) * b.width,
+                                        depth + i * depth_frame_stride, sizeof(float) * depth_row_stride,
+                                        sizeof(float) * b.width, b.height, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->d_depth;
+        depth_row_stride = b.width;
+        depth_frame_stride = (size_t)b.width * b.height;
+    }
+    if (!b.enable_pose) dsrc = nullptr;
+
+    c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
+                      b.fast_threshold, B, /*first_slot=*/S);
+    c->enqueue_match(B, b.ratio, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
+    launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
+                      c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
+    launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
+                              c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
+                              depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
+                              c->d_bpinfo, B, c->stream);
+    if (b.enable_pose && dsrc)
+        launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
+                          b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
+                          c->d_rt, B, c->stream);
+    launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
+                   c->stream);
+    launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost,
+                              c->stream));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));
+    c->submitted = true;
+    c->streams_started = true;
+    return VO_OK;
+}
+
+int vo_batch_wait(vo_ctx *c, vo_frame_result *results)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_wait: nothing submitted");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->submitted = false;
+    if (results)
+        memcpy(results, c->h_pinned, sizeof(vo_frame_result) * c->bcfg.n_streams * c->bcfg.frames_per_stream);
+    return VO_OK;
+}
+
+static int frame_ok(vo_ctx *c, int frame, const char *who)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured || c->submitted) return bfail(c, VO_ERR_STATE, "%s: no completed batch", who);
+    if (frame < 0 || frame >= c->bcfg.n_streams * c->bcfg.frames_per_stream)
+        return bfail(c, VO_ERR_ARG, "%s: frame %d out of range", who, frame);
+    return VO_OK;
+}
+
+int vo_batch_get_features(vo_ctx *c, int frame, vo_kp *kps, uint8_t *desc, int *n_out)
+{
+    int rc = frame_ok(c, frame, "vo_batch_get_features");
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int slot = c->bcfg.n_streams + frame;
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->d_nkp + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = n;
+    if (n > 0 && kps)
+        HIP_TRY(c, hipMemcpy(kps, c->d_kps + (size_t)slot * c->kp_stride, sizeof(vo_kp) * n, hipMemcpyDefault));
+    if (n > 0 && desc)
+        HIP_TRY(c, hipMemcpy(desc, c->d_desc + (size_t)slot * c->kp_stride * 32, (size_t)32 * n, hipMemcpyDefault));
+    return VO_OK;
+}
+
+int vo_batch_get_matches(vo_ctx *c, int frame, int which, vo_match *out, float *pts3, int *n_out)
+{
+    int rc = frame_ok(c, frame, "vo_batch_get_matches");
+    if (rc) return rc;
+    if (which < 0 || which > 2) return bfail(c, VO_ERR_ARG, "vo_batch_get_matches: which must be 0, 1 or 2");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const vo_frame_result *r = reinterpret_cast<const vo_frame_result *>(c->h_pinned) + frame;
+    const int n = which == 0 ? r->n_matches : (which == 1 ? r->n_tracked : r->n_3d);
+    const vo_match *src = (which == 0 ? c->d_final : (which == 1 ? c->d_tracked : c->d_valid)) +
+                          (size_t)frame * c->kp_stride;
+    if (n_out) *n_out = n;
+    if (n > 0 && out) HIP_TRY(c, hipMemcpy(out, src, sizeof(vo_match) * n, hipMemcpyDefault));
+    if (n > 0 && pts3 && which == 2)
+        HIP_TRY(c, hipMemcpy(pts3, c->d_pts3 + (size_t)frame * c->kp_stride * 3, sizeof(float) * 3 * n,
+                             hipMemcpyDefault));
+    return VO_OK;
+}
+
+int vo_batch_get_inliers(vo_ctx *c, int frame, int32_t *inliers, int *n_out)
+{
+    int rc = frame_ok(c, frame, "vo_batch_get_inliers");
+    if (rc) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const vo_frame_result *r = reinterpret_cast<const vo_frame_result *>(c->h_pinned) + frame;
+    if (n_out) *n_out = r->pnp_inliers;
+    if (r->pnp_inliers > 0 && inliers)
+        HIP_TRY(c, hipMemcpy(inliers, c->d_inliers + (size_t)frame * c->kp_stride, sizeof(int) * r->pnp_inliers,
+                             hipMemcpyDefault));
+    return VO_OK;
+}
+
+}  // extern "C"

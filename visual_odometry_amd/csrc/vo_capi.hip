@@ -119,7 +119,7 @@ int vo_ctx::allocate()
     hpad = align_up(cfg.max_height, 16);
     plane_bytes = (size_t)pitch * hpad;
     kp_stride = align_up(cfg.max_features, 8);
-    slots = 2 * B + 2;
+    slots = 2 * B + 3;  // S*(F+1) <= 2B batch slots, two for the single-frame operators, one empty
     cand_cap = cfg.max_width * cfg.max_height / 4 + 64;
     in_frame_bytes = (size_t)cfg.max_width * cfg.max_height * 4;
 
@@ -143,6 +143,25 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMalloc(&d_final, sizeof(vo_match) * (size_t)kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_qslot, sizeof(int) * B));
     HIP_TRY(ctx, hipMalloc(&d_tslot, sizeof(int) * B));
+    HIP_TRY(ctx, hipMalloc(&d_depth, sizeof(float) * (size_t)cfg.max_width * cfg.max_height * B));
+    HIP_TRY(ctx, hipMalloc(&d_ages, sizeof(int) * (size_t)kp_stride * slots));
+    HIP_TRY(ctx, hipMalloc(&d_has_prev, sizeof(int) * B));
+    HIP_TRY(ctx, hipMalloc(&d_filter_flag, sizeof(int) * B));
+    HIP_TRY(ctx, hipMalloc(&d_tracked, sizeof(vo_match) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_valid, sizeof(vo_match) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_pts3, sizeof(float) * 3 * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_bpinfo, sizeof(int) * 2 * B));
+    HIP_TRY(ctx, hipMalloc(&d_inliers, sizeof(int) * (size_t)kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_pose, sizeof(int) * 4 * B));
+    HIP_TRY(ctx, hipMalloc(&d_rt, sizeof(double) * 6 * B));
+    HIP_TRY(ctx, hipMalloc(&d_results, sizeof(vo_frame_result) * B));
+    HIP_TRY(ctx, hipMemset(d_ages, 0, sizeof(int) * (size_t)kp_stride * slots));
+    HIP_TRY(ctx, hipMemset(d_pose, 0, sizeof(int) * 4 * B));
+    HIP_TRY(ctx, hipMemset(d_rt, 0, sizeof(double) * 6 * B));
+    HIP_TRY(ctx, hipMemset(d_bpinfo, 0, sizeof(int) * 2 * B));
+    empty_slot = slots - 1;
+    op_slot0 = slots - 3;
+    op_slot1 = slots - 2;
     HIP_TRY(ctx, hipMemset(d_nkp, 0, sizeof(int) * slots));
     HIP_TRY(ctx, hipMemset(d_score, 0, plane_bytes * B));
 
@@ -162,7 +181,9 @@ int vo_ctx::allocate()
 void vo_ctx::release()
 {
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_count, d_kps, d_desc, d_nkp, d_pattern,
-                    d_partial, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng};
+                    d_partial, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng,
+                    d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
+                    d_inliers, d_pose, d_rt, d_results};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (h_pinned) hipHostFree(h_pinned);
@@ -247,14 +268,14 @@ int vo_detect(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int max_
                     max_features, c->cfg.max_features);
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = stage_image(c, gray, w, h, stride))) return rc;
-    c->enqueue_detect(c->d_in, w, h, w, 0, 1, max_features, fast_threshold, 1, /*first_slot=*/0);
-    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_nkp, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->enqueue_detect(c->d_in, w, h, w, 0, 1, max_features, fast_threshold, 1, c->op_slot0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_nkp + c->op_slot0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if ((rc = finish(c, "vo_detect"))) return rc;
     const int n = *reinterpret_cast<int *>(c->h_pinned);
     *n_out = n;
     if (n > 0) {
-        HIP_TRY(c, hipMemcpy(kps, c->d_kps, sizeof(vo_kp) * n, hipMemcpyDefault));
-        HIP_TRY(c, hipMemcpy(desc, c->d_desc, (size_t)32 * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(kps, c->d_kps + (size_t)c->op_slot0 * c->kp_stride, sizeof(vo_kp) * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(desc, c->d_desc + (size_t)c->op_slot0 * c->kp_stride * 32, (size_t)32 * n, hipMemcpyDefault));
     }
     return VO_OK;
 }
@@ -272,7 +293,7 @@ static int upload_features(vo_ctx *c, int slot, const vo_kp *kps, const uint8_t 
 
 static int set_single_pair(vo_ctx *c)
 {
-    const int q = 0, t = 1;
+    const int q = c->op_slot0, t = c->op_slot1;
     HIP_TRY(c, hipMemcpy(c->d_qslot, &q, sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_tslot, &t, sizeof(int), hipMemcpyHostToDevice));
     return VO_OK;
@@ -287,8 +308,8 @@ int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *trai
     if (nq == 0) return VO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = upload_features(c, 0, nullptr, query, nq))) return rc;
-    if ((rc = upload_features(c, 1, nullptr, train, nt))) return rc;
+    if ((rc = upload_features(c, c->op_slot0, nullptr, query, nq))) return rc;
+    if ((rc = upload_features(c, c->op_slot1, nullptr, train, nt))) return rc;
     if ((rc = set_single_pair(c))) return rc;
     launch_knn2(c->d_desc, (size_t)c->kp_stride * 32, c->d_nkp, c->d_qslot, c->d_tslot, c->kp_stride,
                 c->d_partial, c->kp_stride, 1, c->stream);
@@ -350,8 +371,8 @@ int vo_match_features(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_desc
         return fail(c, VO_ERR_ARG, "vo_match_features: null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = upload_features(c, 0, prev_kps, prev_desc, n_prev))) return rc;
-    if ((rc = upload_features(c, 1, curr_kps, curr_desc, n_curr))) return rc;
+    if ((rc = upload_features(c, c->op_slot0, prev_kps, prev_desc, n_prev))) return rc;
+    if ((rc = upload_features(c, c->op_slot1, curr_kps, curr_desc, n_curr))) return rc;
     if ((rc = set_single_pair(c))) return rc;
     c->enqueue_match(1, ratio, FRansacParams{3.0, 0.99, 1000});
     if ((rc = finish(c, "vo_match_features"))) return rc;

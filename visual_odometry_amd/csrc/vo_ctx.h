@@ -39,6 +39,24 @@ struct vo_ctx {
     uint32_t *d_rng = nullptr;
     int rng_len = 0;
 
+    // pose stage
+    float *d_depth = nullptr;  // staging for depth handed over from the host
+    int *d_ages = nullptr;     // track ages, one row per feature slot
+    int *d_has_prev = nullptr, *d_filter_flag = nullptr;
+    vo_match *d_tracked = nullptr, *d_valid = nullptr;
+    float *d_pts3 = nullptr;
+    int *d_bpinfo = nullptr, *d_inliers = nullptr, *d_pose = nullptr;
+    double *d_rt = nullptr;
+    vo_frame_result *d_results = nullptr;
+
+    // batched pipeline state
+    vo_batch_cfg bcfg{};
+    bool configured = false, submitted = false;
+    bool streams_started = false;     // carry slots hold a previous frame
+    bool first_pairs_linked = false;  // q_slot/has_prev already point at the carry slots
+    int op_slot0 = 0, op_slot1 = 0;   // feature slots used by the single-frame operators
+    int empty_slot = 0;            // feature slot that always holds 0 keypoints
+
     static constexpr size_t kPinnedBytes = 1 << 20;
     void *h_pinned = nullptr;
 

@@ -87,4 +87,38 @@ void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride,
                      uint8_t *mask, double *F, int *info, vo_match *final_m,
                      int pairs, hipStream_t s);
 
+
+// ---- pose stage -------------------------------------------------------------
+
+// Per stream, sequentially over its frames: track ages of the current
+// keypoints from the matches, and the multi-view filter decision.
+void launch_track_ages(const vo_match *final_m, const int *info, int kp_stride, const int *q_slot,
+                       const int *t_slot, const int *has_prev, int streams, int frames, const int *nkp,
+                       int *ages, int *filter_flag, hipStream_t s);
+
+// Per frame: apply the multi-view filter (-> tracked), then back-project the
+// current points through the depth map (-> valid + pts3). out_info = {n_tracked, n_3d}.
+void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_stride, const int *t_slot,
+                               const int *has_prev, const int *nkp, const int *ages, const int *filter_flag,
+                               const float *depth, int width, int height, int depth_stride,
+                               size_t depth_frame_stride, double fx, double fy, double cx, double cy,
+                               vo_match *tracked, vo_match *valid, float *pts3, int *out_info, int batch,
+                               hipStream_t s);
+
+// cv::solvePnPRansac per frame on (pts3 -> prev 2-D point). pose = {success,
+// n_inliers, iters_run, n_points}; rt = rvec[3], tvec[3].
+void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_info, int kp_stride,
+                       const uint32_t *rng_raw, int rng_len, double fx, double fy, double cx, double cy,
+                       int max_iters, double threshold, double confidence, int *inliers, int *pose,
+                       double *rt, int batch, hipStream_t s);
+
+// Copy the features and ages of each stream's last frame into its carry slot.
+void launch_carry(vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int kp_stride, int streams, int frames,
+                  hipStream_t s);
+
+// Gather the per-frame counters and poses into vo_frame_result records.
+void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const int *info,
+                    const int *bp_info, const int *pose, const double *rt, vo_frame_result *out, int batch,
+                    hipStream_t s);
+
 }  // namespace vo
