@@ -212,6 +212,16 @@ int vo_batch_get_matches(vo_ctx *ctx, int frame, int which, vo_match *out,
                          float *pts3, int *n_out);
 int vo_batch_get_inliers(vo_ctx *ctx, int frame, int32_t *inliers, int *n_out);
 
+/* Per-kernel timing of vo_batch_submit (measurement aid; the reference only
+ * clocks detect and match as a whole, src/frame_processor.cpp:30-40).  When
+ * enabled, HIP events are recorded on the context's stream around every
+ * kernel of the batch; vo_batch_get_timing() returns, after vo_batch_wait(),
+ * the milliseconds of each of the vo_batch_stage_count() stages. */
+int vo_batch_set_timing(vo_ctx *ctx, int enable);
+int vo_batch_stage_count(void);
+const char *vo_batch_stage_name(int stage);
+int vo_batch_get_timing(vo_ctx *ctx, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,6 @@ def vga_seq():
 @pytest.fixture(scope="session")
 def ctx():
     from visual_odometry_amd import capi
-    c = capi.Context(device=0, max_width=1920, max_height=1080, max_features=4000, max_batch=4)
+    c = capi.Context(device=0, max_width=1920, max_height=1080, max_features=4000, max_batch=8)
     yield c
     c.close()

@@ -79,6 +79,10 @@ EXPORTS = {
     "vo_batch_get_features": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "vo_batch_get_matches": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vo_batch_get_inliers": (C.c_int, [_P, C.c_int, _P, _P]),
+    "vo_batch_set_timing": (C.c_int, [_P, C.c_int]),
+    "vo_batch_stage_count": (C.c_int, []),
+    "vo_batch_stage_name": (C.c_char_p, [C.c_int]),
+    "vo_batch_get_timing": (C.c_int, [_P, _P]),
 }
 
 _lib = None
@@ -277,3 +281,12 @@ class Context:
         n = C.c_int(0)
         self._check(self._lib.vo_batch_get_inliers(self._h, frame, _ptr(out), C.addressof(n)))
         return out[:n.value].copy()
+
+    def batch_set_timing(self, enable: bool):
+        self._check(self._lib.vo_batch_set_timing(self._h, int(enable)))
+
+    def batch_timing(self) -> dict:
+        n = self._lib.vo_batch_stage_count()
+        ms = np.zeros(n, np.float32)
+        self._check(self._lib.vo_batch_get_timing(self._h, _ptr(ms)))
+        return {self._lib.vo_batch_stage_name(i).decode(): float(ms[i]) for i in range(n)}

@@ -458,7 +458,7 @@ void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride, con
     const size_t lds = ((sizeof(FrShared) + 15) & ~size_t(15)) + sizeof(float4) * (size_t)kp_stride;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_f_ransac),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_f_ransac),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }

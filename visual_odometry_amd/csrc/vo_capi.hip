@@ -102,7 +102,7 @@ vo_ctx *vo_create(int device, const vo_cfg *cfg)
 void vo_destroy(vo_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     c->release();
     delete c;
 }
@@ -185,9 +185,11 @@ void vo_ctx::release()
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results};
     for (void *p : ptrs)
-        if (p) hipFree(p);
-    if (h_pinned) hipHostFree(h_pinned);
-    if (stream) hipStreamDestroy(stream);
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 static int check_frame(vo_ctx *c, int w, int h, const char *who)
@@ -391,21 +393,28 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
                             int channels, int max_features, int fast_threshold, int batch, int first_slot)
 {
     (void)hipMemsetAsync(d_cand_count, 0, sizeof(uint32_t) * batch, stream);
+    mark(0);
     launch_frontend(src, w, h, src_stride, src_frame_stride, channels, PlaneBatch{nullptr, 0, 0},
                     plane(d_score), plane(d_blur), fast_threshold, batch, gc, stream);
+    mark(1);
     launch_nms_emit(plane(d_score), w, h, d_cand, d_cand_count, cand_cap, batch, stream);
+    mark(2);
     launch_select(d_cand, d_cand_count, cand_cap, w, h, max_features, kFBorder,
                   d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot, batch, stream);
+    mark(3);
     launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
                  d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
 }
 
 void vo_ctx::enqueue_match(int pairs, float ratio, FRansacParams prm)
 {
+    mark(4);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
                 pairs, stream);
+    mark(5);
     launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio, d_knn, d_good,
                           d_ngood, pairs, stream);
+    mark(6);
     launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
                     stream);
 }

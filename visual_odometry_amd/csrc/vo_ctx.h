@@ -57,6 +57,15 @@ struct vo_ctx {
     int op_slot0 = 0, op_slot1 = 0;   // feature slots used by the single-frame operators
     int empty_slot = 0;            // feature slot that always holds 0 keypoints
 
+    // optional per-stage timing of the batched pipeline (HIP events on `stream`)
+    static constexpr int kStages = 11;
+    bool timing = false;
+    hipEvent_t ev[kStages + 1] = {};
+    void mark(int i)
+    {
+        if (timing) (void)hipEventRecord(ev[i], stream);
+    }
+
     static constexpr size_t kPinnedBytes = 1 << 20;
     void *h_pinned = nullptr;
 
