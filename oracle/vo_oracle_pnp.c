@@ -115,6 +115,82 @@ static void jacobi_eig_desc(const double *Ain, int n, double *w, double *Vt)
     }
 }
 
+/* Right singular vectors of a rows x 12 matrix G by one-sided (Hestenes)
+ * Jacobi -- the family of method cv::SVD uses -- with the column pairs of
+ * every sweep taken in round-robin (tournament) order so that the six pairs
+ * of a round are disjoint.  w receives the squared singular values in
+ * descending order (ties by column index), row k of Vt the matching vector;
+ * for a symmetric positive semi-definite G these are its eigen-pairs.
+ * G is column-major here: G[12*j + i] is element (i, j). */
+static int rr_partner(int x, int r)
+{
+    if (x == 11) return r;
+    if (x == r) return 11;
+    int y = (2 * r - x) % 11;
+    return y < 0 ? y + 11 : y;
+}
+
+static void svd12_onesided(const double *Gcm, int rows, double *w, double *Vt)
+{
+    double G[12][12], V[12][12];
+    double frob = 0;
+    for (int j = 0; j < 12; j++)
+        for (int i = 0; i < 12; i++) {
+            G[j][i] = i < rows ? Gcm[12 * j + i] : 0.0;
+            V[j][i] = i == j;
+        }
+    for (int j = 0; j < 12; j++)
+        for (int i = 0; i < rows; i++) frob += G[j][i] * G[j][i];
+    const double eps = 1e-15;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int r = 0; r < 11; r++)
+            for (int x = 0; x < 12; x++) {
+                int y = rr_partner(x, r);
+                if (x > y) continue;
+                double *gp = G[x], *gq = G[y];
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < rows; i++) alpha += gp[i] * gp[i];
+                for (int i = 0; i < rows; i++) beta += gq[i] * gq[i];
+                for (int i = 0; i < rows; i++) gamma += gp[i] * gq[i];
+                if (fabs(gamma) <= eps * sqrt(alpha * beta) || fabs(gamma) <= 1e-26 * frob) continue;
+                rotated = 1;
+                double zeta = (beta - alpha) / (2 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                double c = 1 / sqrt(1 + t * t), sn = c * t;
+                for (int i = 0; i < rows; i++) {
+                    double a = gp[i], b = gq[i];
+                    gp[i] = c * a - sn * b;
+                    gq[i] = sn * a + c * b;
+                }
+                double *vp = V[x], *vq = V[y];
+                for (int i = 0; i < 12; i++) {
+                    double a = vp[i], b = vq[i];
+                    vp[i] = c * a - sn * b;
+                    vq[i] = sn * a + c * b;
+                }
+            }
+        if (!rotated) break;
+    }
+    double nrm[12];
+    int order[12];
+    for (int j = 0; j < 12; j++) {
+        double a = 0;
+        for (int i = 0; i < rows; i++) a += G[j][i] * G[j][i];
+        nrm[j] = a;
+        order[j] = j;
+    }
+    for (int i = 1; i < 12; i++) { /* stable insertion sort, descending */
+        int o = order[i], k = i;
+        while (k > 0 && nrm[order[k - 1]] < nrm[o]) { order[k] = order[k - 1]; k--; }
+        order[k] = o;
+    }
+    for (int k = 0; k < 12; k++) {
+        w[k] = nrm[order[k]];
+        for (int i = 0; i < 12; i++) Vt[k * 12 + i] = V[order[k]][i];
+    }
+}
+
 /* nearest rotation to a 3x3 matrix A (U V^T of its SVD), via the
  * eigen-decomposition of A^T A; a vanishing third singular value is
  * completed with a cross product. */
@@ -378,18 +454,39 @@ static int epnp_solve(const double *obj, const double *img, int n, double fu, do
     int ok = 0;
     epnp_control_points(&e);
     if (epnp_barycentric(&e)) {
-        double mtm[144] = {0}, d[12], ut[144];
-        for (int i = 0; i < n; i++) {
-            const double *as = e.alphas + 4 * i;
-            double m1[12], m2[12];
-            for (int k = 0; k < 4; k++) {
-                m1[3 * k] = as[k] * fu; m1[3 * k + 1] = 0.0; m1[3 * k + 2] = as[k] * (uc - img[2 * i]);
-                m2[3 * k] = 0.0; m2[3 * k + 1] = as[k] * fv; m2[3 * k + 2] = as[k] * (vc - img[2 * i + 1]);
+        /* cv: SVD of M^T M (12x12); here the right singular vectors of the
+         * 2n x 12 matrix M itself (same vectors, better conditioned) */
+        double d[12], ut[144];
+        if (n == 5) {
+            double Mcm[144];
+            memset(Mcm, 0, sizeof(Mcm));
+            for (int i = 0; i < n; i++) {
+                const double *as = e.alphas + 4 * i;
+                for (int k = 0; k < 4; k++) {
+                    Mcm[12 * (3 * k) + 2 * i] = as[k] * fu;
+                    Mcm[12 * (3 * k + 1) + 2 * i + 1] = as[k] * fv;
+                    Mcm[12 * (3 * k + 2) + 2 * i] = as[k] * (uc - img[2 * i]);
+                    Mcm[12 * (3 * k + 2) + 2 * i + 1] = as[k] * (vc - img[2 * i + 1]);
+                }
             }
+            svd12_onesided(Mcm, 10, d, ut);
+        } else {
+            double mtm[144] = {0};
+            for (int i = 0; i < n; i++) {
+                const double *as = e.alphas + 4 * i;
+                double m1[12], m2[12];
+                for (int k = 0; k < 4; k++) {
+                    m1[3 * k] = as[k] * fu; m1[3 * k + 1] = 0.0; m1[3 * k + 2] = as[k] * (uc - img[2 * i]);
+                    m2[3 * k] = 0.0; m2[3 * k + 1] = as[k] * fv; m2[3 * k + 2] = as[k] * (vc - img[2 * i + 1]);
+                }
+                for (int a = 0; a < 12; a++)
+                    for (int b = 0; b < 12; b++) mtm[a * 12 + b] += m1[a] * m1[b] + m2[a] * m2[b];
+            }
+            double mcm[144];
             for (int a = 0; a < 12; a++)
-                for (int b = 0; b < 12; b++) mtm[a * 12 + b] += m1[a] * m1[b] + m2[a] * m2[b];
+                for (int b = 0; b < 12; b++) mcm[12 * b + a] = mtm[a * 12 + b];
+            svd12_onesided(mcm, 12, d, ut);
         }
-        jacobi_eig_desc(mtm, 12, d, ut);
 
         /* compute_L_6x10 / compute_rho */
         double L[60], rho[6];
@@ -578,7 +675,12 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
         for (int a = 0; a < 12; a++)
             for (int b = 0; b < 12; b++) LL[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
     }
-    jacobi_eig_desc(LL, 12, LW, LV);
+    {
+        double llcm[144];
+        for (int a = 0; a < 12; a++)
+            for (int b = 0; b < 12; b++) llcm[12 * b + a] = LL[a * 12 + b];
+        svd12_onesided(llcm, 12, LW, LV);
+    }
     double RRt[12];
     memcpy(RRt, LV + 11 * 12, sizeof(RRt));
     double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};

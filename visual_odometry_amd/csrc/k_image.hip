@@ -273,14 +273,20 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
 // Thread = four adjacent score bytes.  A corner survives when its score is
 // strictly greater than all eight neighbours (cv::FAST with
 // nonmaxSuppression=true, reference src/feature_detector.cpp:59).  Survivors
-// are compacted per wave with ballots and appended with one atomic per wave.
-__global__ __launch_bounds__(256) void k_nms_emit(PlaneBatch score, int width, int height,
-                                                  uint32_t *__restrict__ cand,
-                                                  uint32_t *__restrict__ cand_count, int cand_cap)
+// are compacted with wave ballots and an LDS prefix over the block's waves,
+// so each 256x16-pixel block issues a single global atomic.
+constexpr int NMS_THREADS = 1024;
+constexpr int NMS_ROWS = NMS_THREADS / 64;
+
+__global__ __launch_bounds__(NMS_THREADS) void k_nms_emit(PlaneBatch score, int width, int height,
+                                                          uint32_t *__restrict__ cand,
+                                                          uint32_t *__restrict__ cand_count, int cand_cap)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_wave[NMS_ROWS];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y * NMS_ROWS + wave;
     const int x = gx * 4;
     const int f = blockIdx.z;
     const uint8_t *plane = score.base + f * score.plane_stride;
@@ -318,20 +324,26 @@ __global__ __launch_bounds__(256) void k_nms_emit(PlaneBatch score, int width, i
         }
     }
 
-    // wave compaction: one atomic per wave
     uint64_t m[4];
-    int total = 0;
+    uint32_t total = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         m[i] = __ballot((flags >> i) & 1u);
-        total += __popcll(m[i]);
+        total += (uint32_t)__popcll(m[i]);
     }
+    if (lane == 0) s_wave[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < NMS_ROWS; w++) tot += s_wave[w];
+        s_base = tot ? atomicAdd(&cand_count[f], tot) : 0u;
+    }
+    __syncthreads();
     if (total == 0) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[f], (uint32_t)total);
-    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t off = s_base;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t off = base;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if ((flags >> i) & 1u) {
@@ -347,8 +359,9 @@ __global__ __launch_bounds__(256) void k_nms_emit(PlaneBatch score, int width, i
 void launch_nms_emit(PlaneBatch score, int width, int height, uint32_t *cand, uint32_t *cand_count,
                      int cand_cap, int batch, hipStream_t s)
 {
-    dim3 grid((width + 255) / 256, (height + 3) / 4, batch);
-    hipLaunchKernelGGL(k_nms_emit, grid, dim3(256), 0, s, score, width, height, cand, cand_count, cand_cap);
+    dim3 grid((width + 255) / 256, (height + NMS_ROWS - 1) / NMS_ROWS, batch);
+    hipLaunchKernelGGL(k_nms_emit, grid, dim3(NMS_THREADS), 0, s, score, width, height, cand, cand_count,
+                       cand_cap);
 }
 
 // ---------------------------------------------------------------- select
