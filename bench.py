@@ -117,10 +117,9 @@ def main():
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from visual_odometry_amd import shard
+    fps = shard.aggregate_fps(B * args.steps, elapsed, dist, "cuda")
+    elapsed = shard.max_over_ranks(elapsed, dist, "cuda")
 
     # per-kernel durations with HIP events on the library's own stream
     ctx.batch_set_timing(True)
@@ -133,7 +132,6 @@ def main():
     ctx.batch_set_timing(False)
 
     if rank == 0:
-        fps = world * B * args.steps / elapsed
         n_kp = float(res["n_keypoints"].mean())
         cand_bytes = 4.0
         # algorithmic work per launch (one launch covers the whole batch of B frames)

@@ -1,0 +1,299 @@
+"""CPU-only checks of the oracle itself: known answers that do not depend on
+OpenCV quirks, plus committed golden hashes that pin its outputs.
+
+PARITY UNPINNED: the reference ships no tests or vectors and OpenCV is not
+installed, so these are semantic checks (what the operator must mean), not
+comparisons with the reference's binaries."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "oracle_hashes.json")
+
+
+def test_pattern_table_hash():
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "vo_orb_pattern.h")).read()
+    body = src[src.index("{", src.index("vo_orb_bit_pattern_31")) + 1: src.rindex("}")]
+    ints = [int(x) for x in re.findall(r"-?\d+", body)]
+    assert len(ints) == 1024 and min(ints) == -13 and max(ints) == 12
+    digest = hashlib.sha256(",".join(map(str, ints)).encode()).hexdigest()
+    assert digest == "88df8ca875cc8db56799edd57bb914edad8acb2d48c202b7a464a575b55dbdb8"
+    # structural property of the ORB table: x1 <= x2 in every test
+    a = np.array(ints).reshape(256, 4)
+    assert (a[:, 0] <= a[:, 2]).all()
+
+
+def test_pattern_rotated_by_minus_one_degree_is_identity():
+    """FAST keypoints carry angle -1; ORB rotates the pattern by it and rounds."""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "vo_orb_pattern.h")).read()
+    body = src[src.index("{", src.index("vo_orb_bit_pattern_31")) + 1: src.rindex("}")]
+    p = np.array([int(x) for x in re.findall(r"-?\d+", body)], np.float32).reshape(512, 2)
+    ang = np.float32(-1.0) * np.float32(np.pi / 180.0)
+    a, b = np.float32(np.cos(np.float64(ang))), np.float32(np.sin(np.float64(ang)))
+    x = p[:, 0] * a - p[:, 1] * b
+    y = p[:, 0] * b + p[:, 1] * a
+    assert np.array_equal(np.rint(x), p[:, 0]) and np.array_equal(np.rint(y), p[:, 1])
+
+
+def test_rng_mwc_known_answers(oracle):
+    # state' = (uint32)state * 4164903690 + (state >> 32), seed 2^64-1
+    out = oracle.rng_stream(4)
+    s = (1 << 64) - 1
+    exp = []
+    for _ in range(4):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & ((1 << 64) - 1)
+        exp.append(s & 0xFFFFFFFF)
+    assert out.tolist() == exp
+    assert exp[0] == 130063605
+
+
+def test_gray_formula(oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (33, 47, 3), dtype=np.uint8)
+    exp = ((img[..., 0].astype(np.int64) * 3735 + img[..., 1].astype(np.int64) * 19235
+            + img[..., 2].astype(np.int64) * 9798 + 16384) >> 15).astype(np.uint8)
+    assert np.array_equal(oracle.gray(img), exp)
+    white = np.full((4, 4, 3), 255, np.uint8)
+    assert (oracle.gray(white) == 255).all()
+
+
+_RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+         (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def _is_corner(img, x, y, t):
+    v = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in _RING]
+    for sign in (1, -1):
+        flags = [(p - v) * sign > t for p in ring]
+        ext = flags + flags[:8]
+        run = 0
+        for f in ext:
+            run = run + 1 if f else 0
+            if run >= 9:
+                return True
+    return False
+
+
+def test_fast_score_is_largest_passing_threshold(oracle):
+    """score(x) = max t for which the 9-of-16 segment test still passes; 0 if it fails at thr."""
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (24, 28), dtype=np.uint8)
+    img[8:16, 10:20] = 200  # a bright block gives real corners
+    thr = 15
+    sm = oracle.fast_score_map(img, thr)
+    n_corners = 0
+    for y in range(3, 21):
+        for x in range(3, 25):
+            if _is_corner(img, x, y, thr):
+                n_corners += 1
+                s = int(sm[y, x])
+                assert s >= thr and _is_corner(img, x, y, s) and not _is_corner(img, x, y, s + 1)
+            else:
+                assert sm[y, x] == 0
+    assert n_corners > 5
+    assert (sm[:3] == 0).all() and (sm[-3:] == 0).all() and (sm[:, :3] == 0).all() and (sm[:, -3:] == 0).all()
+
+
+def test_fast_nms_strict_and_raster_order(oracle):
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (60, 80), dtype=np.uint8)
+    sm = oracle.fast_score_map(img, 10).astype(np.int32)
+    kps = oracle.fast(img, 10)
+    pad = np.pad(sm, 1)
+    exp = []
+    for y in range(60):
+        for x in range(80):
+            s = sm[y, x]
+            nb = pad[y:y + 3, x:x + 3].copy()
+            nb[1, 1] = -1
+            if s > 0 and (s > nb).all():
+                exp.append((x, y, s))
+    got = [(int(k["x"]), int(k["y"]), int(k["response"])) for k in kps]
+    assert got == exp and len(got) > 10
+    assert (kps["size"] == 7).all() and (kps["angle"] == -1).all() and (kps["octave"] == 0).all()
+
+
+def test_blur_kernel_and_borders(oracle):
+    rng = np.random.default_rng(2)
+    g = rng.integers(0, 256, (20, 23), dtype=np.uint8)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    pad = np.pad(g.astype(np.int64), 3, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+    h = sum(k[i] * pad[:, i:i + 23] for i in range(7))
+    v = sum(k[i] * h[i:i + 20] for i in range(7))
+    exp = np.minimum((v + 32768) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(oracle.blur7(g), exp)
+
+
+def test_brief_bits(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (80, 90), dtype=np.uint8)
+    kps = np.zeros(2, oracle.KP_DTYPE)
+    kps["x"] = [40, 45]; kps["y"] = [35, 44]; kps["angle"] = -1; kps["size"] = 7
+    d = oracle.brief(img, kps)
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "include", "vo_orb_pattern.h")).read()
+    body = src[src.index("{", src.index("vo_orb_bit_pattern_31")) + 1: src.rindex("}")]
+    pat = np.array([int(x) for x in re.findall(r"-?\d+", body)]).reshape(256, 4)
+    for i, (x, y) in enumerate([(40, 35), (45, 44)]):
+        bits = [int(img[y + p[1], x + p[0]] < img[y + p[3], x + p[2]]) for p in pat]
+        exp = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert np.array_equal(d[i], exp)
+
+
+def test_select_top_canonical_order(oracle, vga_seq):
+    g = oracle.gray(vga_seq["frames"][0])
+    allk = oracle.fast(g, 20)
+    k, _ = oracle.detect(g, 300, 20)
+    order = np.lexsort((allk["y"] * 640 + allk["x"], -allk["response"]))[:300]
+    top = allk[order]
+    inside = (top["x"] >= 31) & (top["x"] < 640 - 31) & (top["y"] >= 31) & (top["y"] < 480 - 31)
+    assert np.array_equal(k, top[inside])
+
+
+def test_knn2_against_numpy(oracle):
+    rng = np.random.default_rng(8)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    t[10] = t[3]; t[50] = t[3]; q[5] = t[3]  # exact ties: lower index first
+    knn = oracle.knn2(q, t)
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    for i in range(40):
+        order = np.lexsort((np.arange(70), d[i]))
+        assert (knn["idx0"][i], knn["dist0"][i]) == (order[0], d[i][order[0]])
+        assert (knn["idx1"][i], knn["dist1"][i]) == (order[1], d[i][order[1]])
+    assert knn["idx0"][5] == 3 and knn["idx1"][5] == 10 and knn["dist1"][5] == 0
+
+
+def _two_view(rng, n, noise=0.0):
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    X = np.stack([rng.uniform(-2500, 2500, n), rng.uniform(-1400, 1400, n), rng.uniform(2500, 7000, n)], 1)
+    rv = np.array([0.02, -0.03, 0.01]); t = np.array([120.0, -40.0, 60.0])
+    th = np.linalg.norm(rv); k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    Y = X @ R.T + t
+    p1 = np.stack([X[:, 0] / X[:, 2] * cam.fx + cam.cx, X[:, 1] / X[:, 2] * cam.fy + cam.cy], 1)
+    p2 = np.stack([Y[:, 0] / Y[:, 2] * cam.fx + cam.cx, Y[:, 1] / Y[:, 2] * cam.fy + cam.cy], 1)
+    p2 = p2 + rng.normal(0, noise, p2.shape) if noise else p2
+    return cam, X, R, rv, t, p1.astype(np.float32), p2.astype(np.float32)
+
+
+def test_seven_point_solver_exact_data(oracle):
+    rng = np.random.default_rng(21)
+    cam, X, R, rv, t, p1, p2 = _two_view(rng, 60)
+    Fs = oracle.f7(p1[:7], p2[:7])
+    assert 1 <= len(Fs) <= 3
+    # one of the solutions explains all 60 noise-free points (sub-0.01 px epipolar distance)
+    errs = [oracle.f_error(p1, p2, F).max() for F in Fs]
+    assert min(errs) < 1e-4
+    for F in Fs:
+        assert abs(np.linalg.det(F.reshape(3, 3) / np.linalg.norm(F))) < 1e-9
+        assert oracle.f_error(p1[:7], p2[:7], F).max() < 1e-6
+
+
+def test_fundamental_ransac_labels_outliers(oracle):
+    rng = np.random.default_rng(22)
+    cam, X, R, rv, t, p1, p2 = _two_view(rng, 500, noise=0.3)
+    bad = rng.random(500) < 0.4
+    p2[bad] = rng.uniform([0, 0], [1280, 720], (int(bad.sum()), 2)).astype(np.float32)
+    ok, F, mask, iters = oracle.find_fundamental_ransac(p1, p2)
+    assert ok and 1 <= iters <= 1000
+    m = mask.astype(bool)
+    assert m[~bad].mean() > 0.97      # inliers kept
+    assert m[bad].mean() < 0.15       # random outliers rarely fall within 3 px of an epipolar line
+    ok2, F2, mask2, it2 = oracle.find_fundamental_ransac(p1, p2)
+    assert np.array_equal(mask, mask2) and it2 == iters  # fixed seed: deterministic
+
+
+def test_fundamental_ransac_small_sets(oracle):
+    rng = np.random.default_rng(23)
+    cam, X, R, rv, t, p1, p2 = _two_view(rng, 14)
+    ok, F, mask, iters = oracle.find_fundamental_ransac(p1, p2)
+    assert not ok and mask.sum() == 0  # < 15 points: LMedS branch, not restated
+
+
+def test_rodrigues_roundtrip(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        r = rng.normal(0, 0.7, 3)
+        R = oracle.rodrigues(r)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        assert np.allclose(oracle.rodrigues(R), r, atol=1e-10)
+    assert np.array_equal(oracle.rodrigues(np.zeros(3)), np.eye(3))
+
+
+def test_pnp_ransac_recovers_pose(oracle):
+    rng = np.random.default_rng(31)
+    cam, X, R, rv, t, p1, p2 = _two_view(rng, 400, noise=0.4)
+    bad = rng.random(400) < 0.3
+    p2[bad] = rng.uniform([0, 0], [1280, 720], (int(bad.sum()), 2)).astype(np.float32)
+    ok, r, tt, inl = oracle.solve_pnp_ransac(X.astype(np.float32), p2, cam.fx, cam.fy, cam.cx, cam.cy)
+    assert ok
+    assert np.abs(r - rv).max() < 2e-3 and np.abs(tt - t).max() < 8.0
+    assert set(inl) >= set(np.flatnonzero(~bad)[:50]) and len(inl) < (~bad).sum() + 15
+    assert (np.diff(inl) > 0).all()
+
+
+def test_backproject_and_track_filter(oracle):
+    m = np.zeros(4, oracle.MATCH_DTYPE)
+    m["query"] = [0, 1, 2, 3]; m["train"] = [3, 2, 1, 0]
+    m["cx"] = [10.4, 20.5, 5.0, 300.0]; m["cy"] = [4.6, 7.5, 5.0, 2.0]
+    depth = np.full((16, 32), 1000.0, np.float32)
+    depth[5, 10] = 2000.0   # (round(10.4), round(4.6))
+    depth[8, 21] = np.nan   # round half away from zero: (21, 8)
+    depth[5, 5] = 30.0      # below 50 mm
+    mv, p3 = oracle.backproject(m, depth, 100.0, 100.0, 16.0, 8.0)
+    assert len(mv) == 1 and mv["query"][0] == 0
+    assert np.allclose(p3[0], [(10.4 - 16) * 2000 / 100, (4.6 - 8) * 2000 / 100, 2000], rtol=1e-6)
+    # ages: trainIdx inherits queryIdx's age + 1; the filter needs > 80 matches and >= 50 mature
+    n = 100
+    mm = np.zeros(n, oracle.MATCH_DTYPE)
+    mm["query"] = np.arange(n); mm["train"] = np.arange(n)[::-1]
+    prev = np.where(np.arange(n) < 60, 2, 0).astype(np.int32)
+    out, ages = oracle.track_filter(mm, prev, n)
+    assert len(out) == 60 and (ages[mm["train"][:60]] == 3).all() and (ages[mm["train"][60:]] == 1).all()
+    out2, _ = oracle.track_filter(mm[:80], prev, n)
+    assert len(out2) == 80  # not more than 80 matches: no filtering
+
+
+def _digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _golden_cases(oracle):
+    cam = synth.Camera(320, 240, 260.0, 260.0, 159.5, 119.5)
+    seq = synth.make_sequence(cam, 2, seed=4242, channels=3)
+    g0, g1 = oracle.gray(seq["frames"][0]), oracle.gray(seq["frames"][1])
+    k0, d0 = oracle.detect(g0, 400, 20)
+    k1, d1 = oracle.detect(g1, 400, 20)
+    knn = oracle.knn2(d0, d1)
+    m, mask, nr = oracle.match_filter(knn, len(k1), k0, k1, 0.7)
+    return {
+        "input_frames": _digest(seq["frames"]),
+        "gray": _digest(g0, g1),
+        "fast_score_map": _digest(oracle.fast_score_map(g0, 20)),
+        "blur7": _digest(oracle.blur7(g0)),
+        "detect_kps": _digest(k0, k1),
+        "detect_desc": _digest(d0, d1),
+        "knn2": _digest(knn),
+        "ransac_mask": _digest(mask),
+        "matches": _digest(m),
+    }
+
+
+def test_golden_hashes(oracle):
+    """Committed SHA-256 of oracle outputs on a seeded input (tests/golden/make_golden.py)."""
+    got = _golden_cases(oracle)
+    exp = json.load(open(GOLDEN))
+    assert got == exp
