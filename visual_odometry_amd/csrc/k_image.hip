@@ -1,6 +1,7 @@
-// Image-side kernels of the detector for gfx950: BGR->gray, the fused
-// FAST-9/16 score + 7x7 Gaussian tile kernel, non-max suppression with
-// wave-ballot compaction, top-N selection and rBRIEF-256.
+// Image-side kernels of the detector for gfx950: BGR->gray, the fused tile
+// kernel (gray + FAST-9/16 pre-test, ballot-compacted scoring, non-max
+// suppression, candidate emission and 7x7 Gaussian), top-N selection and
+// rBRIEF-256.
 //
 // All arithmetic here is 8/16/32-bit integer and bit-exact by construction;
 // the work is HBM/LDS/VALU integer work, there is nothing MFMA-shaped.
@@ -81,14 +82,18 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride, size
                            src_frame_stride, dst, c);
 }
 
-// ------------------------------------------------ fused FAST score + blur
+// ----------------------- fused gray + FAST + NMS + emit + blur (one tile)
 
 constexpr int FE_TW = 128;             // interior tile width
 constexpr int FE_TH = 16;              // interior tile height
-constexpr int FE_HALO = 3;             // FAST ring radius == blur radius
-constexpr int FE_GPITCH = FE_TW + 16;  // LDS gray row: image x0-4 .. x0+TW+11, 16-B aligned
-constexpr int FE_GROWS = FE_TH + 2 * FE_HALO;
+constexpr int FE_PITCH = FE_TW + 16;   // LDS row: image x0-4 .. x0+TW+11, 16-B aligned
+constexpr int FE_GROWS = FE_TH + 8;    // gray rows: image y0-4 .. y0+TH+3
+constexpr int FE_SROWS = FE_TH + 2;    // score rows: image y0-1 .. y0+TH
+constexpr int FE_HROWS = FE_TH + 6;    // row-sum rows: image y0-3 .. y0+TH+2
 constexpr int FE_THREADS = 512;
+constexpr int FE_WAVES = FE_THREADS / 64;
+constexpr int FE_QCAP = (FE_TW + 2) * (FE_TH + 2);
+constexpr int FE_HALO_PIX = 2 * (FE_TW + 2) + 2 * FE_TH;
 
 // FAST-9/16 score of one pixel from its 16 ring values p[] and centre v:
 //   A = max over the 16 arcs of 9 of min(v - p) = v - min_arcs(max_arc p)
@@ -115,26 +120,19 @@ __device__ __forceinline__ uint32_t fast_score(const uint32_t (&p)[16], uint32_t
     return sc >= thr ? (uint32_t)sc : 0u;
 }
 
-// ring value k (OpenCV order, dx/dy below) for pixel i of a 4-pixel group,
-// taken from the seven row windows w[row][3]; tile column of pixel i is 4+i.
-//   k : 0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15
-//   dx: 0 1 2 3 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1
-//   dy: 3 3 2 1 0 -1 -2 -3 -3 -3 -2 -1 0 1 2 3
-#define FE_RING(I, K, DX, DY) p[K] = win_byte<4 + I + (DX)>(w[3 + (DY)][0], w[3 + (DY)][1], w[3 + (DY)][2])
-
-template <int I>
-__device__ __forceinline__ uint32_t fast_pixel(const uint32_t (&w)[7][3], int thr)
+// Necessary condition for a 9-arc on the 16-ring: the arc contains at least
+// one pixel of every opposite pair, so both the vertical pair (p0, p8) and the
+// horizontal pair (p4, p12) must hold a pixel brighter than v+t, or both a
+// pixel darker than v-t.  Rejects about 92 % of the pixels of a textured frame.
+__device__ __forceinline__ bool fast_quick(uint32_t v, uint32_t p0, uint32_t p8, uint32_t p4, uint32_t p12, int thr)
 {
-    uint32_t p[16];
-    FE_RING(I, 0, 0, 3);   FE_RING(I, 1, 1, 3);   FE_RING(I, 2, 2, 2);    FE_RING(I, 3, 3, 1);
-    FE_RING(I, 4, 3, 0);   FE_RING(I, 5, 3, -1);  FE_RING(I, 6, 2, -2);   FE_RING(I, 7, 1, -3);
-    FE_RING(I, 8, 0, -3);  FE_RING(I, 9, -1, -3); FE_RING(I, 10, -2, -2); FE_RING(I, 11, -3, -1);
-    FE_RING(I, 12, -3, 0); FE_RING(I, 13, -3, 1); FE_RING(I, 14, -2, 2);  FE_RING(I, 15, -1, 3);
-    const uint32_t v = win_byte<4 + I>(w[3][0], w[3][1], w[3][2]);
-    return fast_score(p, v, thr);
+    const int hi = (int)v + thr, lo = (int)v - thr;
+    const bool b = (int)max(p0, p8) > hi && (int)max(p4, p12) > hi;
+    const bool d = (int)min(p0, p8) < lo && (int)min(p4, p12) < lo;
+    return b || d;
 }
 
-// 7-tap row sum of pixel i (tile column 4+i) from one row window
+// 7-tap row sum of pixel i (window byte 4+i) from one 12-byte row window
 template <int I>
 __device__ __forceinline__ uint32_t hsum7(uint32_t d0, uint32_t d1, uint32_t d2)
 {
@@ -144,94 +142,245 @@ __device__ __forceinline__ uint32_t hsum7(uint32_t d0, uint32_t d1, uint32_t d2)
            55u * win_byte<4 + I>(d0, d1, d2);
 }
 
-// One block = one 128x16 tile of one frame.  Stage the tile plus a 3-px halo
-// in LDS as 8-bit gray (converting from BGR/BGRA on the way when CN > 1),
-// then every thread owns four adjacent pixels: FAST score from seven 12-byte
-// row windows, Gaussian through an LDS buffer of 16-bit row sums.
+template <int I>
+__device__ __forceinline__ bool quick_px(const uint32_t (&up)[3], const uint32_t (&mid)[3], const uint32_t (&dn)[3],
+                                         int thr)
+{
+    return fast_quick(win_byte<4 + I>(mid[0], mid[1], mid[2]), win_byte<4 + I>(dn[0], dn[1], dn[2]),
+                      win_byte<4 + I>(up[0], up[1], up[2]), win_byte<7 + I>(mid[0], mid[1], mid[2]),
+                      win_byte<1 + I>(mid[0], mid[1], mid[2]), thr);
+}
+
+// strict 3x3 maximum test of window byte 4+I of the middle row
+template <int I>
+__device__ __forceinline__ bool nms_px(const uint32_t (&a)[3], const uint32_t (&m)[3], const uint32_t (&b)[3])
+{
+    const uint32_t s = win_byte<4 + I>(m[0], m[1], m[2]);
+    if (!s) return false;
+    return s > win_byte<3 + I>(a[0], a[1], a[2]) && s > win_byte<4 + I>(a[0], a[1], a[2]) &&
+           s > win_byte<5 + I>(a[0], a[1], a[2]) && s > win_byte<3 + I>(m[0], m[1], m[2]) &&
+           s > win_byte<5 + I>(m[0], m[1], m[2]) && s > win_byte<3 + I>(b[0], b[1], b[2]) &&
+           s > win_byte<4 + I>(b[0], b[1], b[2]) && s > win_byte<5 + I>(b[0], b[1], b[2]);
+}
+
+// One block = one 128x16 tile of one frame.
+//   0. stage the tile plus a 4-px apron in LDS as 8-bit gray (BGR/BGRA are
+//      converted on the way in);
+//   1. cheap FAST pre-test on the tile and its 1-px rim; survivors are queued
+//      in LDS (wave ballot + one LDS atomic per wave);
+//   2. the queue is processed densely: full FAST-9/16 score into an LDS score tile;
+//   3. 3x3 strict non-max suppression on the tile (cv::FAST, nonmaxSuppression
+//      = true), survivors appended to the frame's candidate list as keys
+//      ((255-score) << 24) | raster index, one global atomic per block;
+//   4. 7x7 Gaussian through 16-bit row sums.
+// tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
 template <int CN>
 __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
                                                          int height, int src_stride,
                                                          size_t src_frame_stride, PlaneBatch gray_out,
                                                          PlaneBatch score, PlaneBatch blur, int thr,
-                                                         GrayCoeffs c)
+                                                         GrayCoeffs c, uint32_t *__restrict__ cand,
+                                                         uint32_t *__restrict__ cand_count, int cand_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_GPITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_hsum[FE_GROWS * FE_TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hsum[FE_HROWS * FE_TW];
+    __shared__ uint16_t s_queue[FE_QCAP];
+    __shared__ uint32_t s_qcount, s_base;
+    __shared__ uint32_t s_wave[FE_WAVES];
 
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * FE_TW, y0 = blockIdx.y * FE_TH;
     const int f = blockIdx.z;
     const uint8_t *img = src + f * src_frame_stride;
 
-    // stage: tile column tc <-> image x0 - 4 + tc, tile row tr <-> image y0 - 3 + tr
-    for (int i = threadIdx.x; i < FE_GROWS * (FE_GPITCH / 4); i += FE_THREADS) {
-        const int tr = i / (FE_GPITCH / 4), tq = i % (FE_GPITCH / 4);
-        const int yy = reflect101(y0 - FE_HALO + tr, height);
-        const uint8_t *row = img + (size_t)yy * src_stride;
+    // ---- 0. stage
+    const bool inside = x0 >= 4 && x0 + FE_PITCH - 4 <= width && y0 >= 4 && y0 + FE_GROWS - 4 <= height;
+    for (int i = tid; i < FE_GROWS * (FE_PITCH / 4); i += FE_THREADS) {
+        const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
         uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int xx = reflect101(x0 - 4 + tq * 4 + j, width);
-            uint32_t g;
+        if (inside) {
+            const uint8_t *row = img + (size_t)(y0 - 4 + tr) * src_stride;
+            const int xb = x0 - 4 + tq * 4;
             if (CN == 1) {
-                g = row[xx];
+#pragma unroll
+                for (int j = 0; j < 4; j++) packed |= (uint32_t)row[xb + j] << (8 * j);
             } else if (CN == 4) {
-                const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
-                g = gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)(xb + j) * 4);
+                    packed |= gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c) << (8 * j);
+                }
             } else {
-                const uint8_t *p = row + (size_t)xx * 3;
-                g = gray_of(p[0], p[1], p[2], c);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint8_t *p = row + (size_t)(xb + j) * 3;
+                    packed |= gray_of(p[0], p[1], p[2], c) << (8 * j);
+                }
             }
-            packed |= g << (8 * j);
+        } else {
+            const int yy = reflect101(y0 - 4 + tr, height);
+            const uint8_t *row = img + (size_t)yy * src_stride;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int xx = reflect101(x0 - 4 + tq * 4 + j, width);
+                uint32_t g;
+                if (CN == 1) {
+                    g = row[xx];
+                } else if (CN == 4) {
+                    const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
+                    g = gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c);
+                } else {
+                    const uint8_t *p = row + (size_t)xx * 3;
+                    g = gray_of(p[0], p[1], p[2], c);
+                }
+                packed |= g << (8 * j);
+            }
         }
-        *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_GPITCH + tq * 4]) = packed;
+        *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) = packed;
     }
+    for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
+    if (tid == 0) s_qcount = 0;
     __syncthreads();
 
-    const int gx = threadIdx.x & 31, gy = threadIdx.x >> 5;  // 32 groups x 16 rows
-    const int x = x0 + gx * 4, y = y0 + gy;
+    const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
+    const int x = x0 + gx * 4, y = y0 + gy;  // image position of the first of them
+    const bool want_fast = score.base != nullptr || cand != nullptr;
 
-    // horizontal pass of the Gaussian for all 22 staged rows
+    if (want_fast) {
+        // ---- 1. pre-test: interior (four pixels per thread) ...
+        uint32_t pass = 0;
+        if (y >= 3 && y < height - 3) {
+            uint32_t up[3], mid[3], dn[3];
+            const uint32_t *ru = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 1) * FE_PITCH + gx * 4]);
+            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4]);
+            const uint32_t *rd = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 7) * FE_PITCH + gx * 4]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { up[k] = ru[k]; mid[k] = rm[k]; dn[k] = rd[k]; }
+            pass = (quick_px<0>(up, mid, dn, thr) && x + 0 >= 3 && x + 0 < width - 3 ? 1u : 0u) |
+                   (quick_px<1>(up, mid, dn, thr) && x + 1 >= 3 && x + 1 < width - 3 ? 2u : 0u) |
+                   (quick_px<2>(up, mid, dn, thr) && x + 2 >= 3 && x + 2 < width - 3 ? 4u : 0u) |
+                   (quick_px<3>(up, mid, dn, thr) && x + 3 >= 3 && x + 3 < width - 3 ? 8u : 0u);
+        }
+        // ... and the 1-px rim around the tile (one pixel per thread)
+        int hr = -1, hc = 0;
+        if (tid < FE_HALO_PIX) {
+            if (tid < FE_TW + 2) { hr = 3; hc = 3 + tid; }
+            else if (tid < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + tid - (FE_TW + 2); }
+            else if (tid < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + tid - 2 * (FE_TW + 2); hc = 3; }
+            else { hr = 4 + tid - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
+            const int ix = x0 - 4 + hc, iy = y0 - 4 + hr;
+            bool ok = ix >= 3 && ix < width - 3 && iy >= 3 && iy < height - 3;
+            if (ok) {
+                const uint8_t *p = &s_gray[hr * FE_PITCH + hc];
+                ok = fast_quick(p[0], p[3 * FE_PITCH], p[-3 * FE_PITCH], p[3], p[-3], thr);
+            }
+            if (!ok) hr = -1;
+        }
+        // queue the survivors: one LDS atomic per wave
+        {
+            uint64_t m[5];
+            uint32_t total = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { m[i] = __ballot((pass >> i) & 1u); total += (uint32_t)__popcll(m[i]); }
+            m[4] = __ballot(hr >= 0);
+            total += (uint32_t)__popcll(m[4]);
+            uint32_t base = 0;
+            if (total) {
+                if (lane == 0) base = atomicAdd(&s_qcount, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if ((pass >> i) & 1u)
+                        s_queue[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
+                    base += (uint32_t)__popcll(m[i]);
+                }
+                if (hr >= 0) s_queue[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. full score of the queued pixels
+        const int qn = (int)s_qcount;
+        for (int e = tid; e < qn; e += FE_THREADS) {
+            const int q = s_queue[e];
+            const int r = q >> 8, cc = q & 255;
+            const uint8_t *p = &s_gray[r * FE_PITCH + cc];
+            uint32_t ring[16];
+            ring[0] = p[3 * FE_PITCH];       ring[1] = p[3 * FE_PITCH + 1];   ring[2] = p[2 * FE_PITCH + 2];
+            ring[3] = p[FE_PITCH + 3];       ring[4] = p[3];                  ring[5] = p[-FE_PITCH + 3];
+            ring[6] = p[-2 * FE_PITCH + 2];  ring[7] = p[-3 * FE_PITCH + 1];  ring[8] = p[-3 * FE_PITCH];
+            ring[9] = p[-3 * FE_PITCH - 1];  ring[10] = p[-2 * FE_PITCH - 2]; ring[11] = p[-FE_PITCH - 3];
+            ring[12] = p[-3];                ring[13] = p[FE_PITCH - 3];      ring[14] = p[2 * FE_PITCH - 2];
+            ring[15] = p[3 * FE_PITCH - 1];
+            s_score[(r - 3) * FE_PITCH + cc] = (uint8_t)fast_score(ring, p[0], thr);
+        }
+        __syncthreads();
+
+        // ---- 3. non-max suppression + emission (score row sr <-> tile row sr + 3)
+        uint32_t sa[3], sm[3], sb[3];
+        {
+            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_score[(gy + 0) * FE_PITCH + gx * 4]);
+            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_score[(gy + 1) * FE_PITCH + gx * 4]);
+            const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_score[(gy + 2) * FE_PITCH + gx * 4]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { sa[k] = ra[k]; sm[k] = rm[k]; sb[k] = rb[k]; }
+        }
+        if (score.base)  // planes are padded to whole tiles: always in bounds
+            *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) = sm[1];
+        if (cand) {
+            uint32_t flags = 0;
+            if (sm[1]) {
+                flags = (nms_px<0>(sa, sm, sb) ? 1u : 0u) | (nms_px<1>(sa, sm, sb) ? 2u : 0u) |
+                        (nms_px<2>(sa, sm, sb) ? 4u : 0u) | (nms_px<3>(sa, sm, sb) ? 8u : 0u);
+            }
+            uint64_t m[4];
+            uint32_t total = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { m[i] = __ballot((flags >> i) & 1u); total += (uint32_t)__popcll(m[i]); }
+            if (lane == 0) s_wave[wave] = total;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tot = 0;
+#pragma unroll
+                for (int w = 0; w < FE_WAVES; w++) tot += s_wave[w];
+                s_base = tot ? atomicAdd(&cand_count[f], tot) : 0u;
+            }
+            __syncthreads();
+            if (total) {
+                uint32_t off = s_base;
+                for (int w = 0; w < wave; w++) off += s_wave[w];
+                const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if ((flags >> i) & 1u) {
+                        const uint32_t slot = off + __popcll(m[i] & lt);
+                        const uint32_t sc = (sm[1] >> (8 * i)) & 255u;
+                        if (slot < (uint32_t)cand_cap)
+                            cand[(size_t)f * cand_cap + slot] = ((255u - sc) << 24) | (uint32_t)(y * width + x + i);
+                    }
+                    off += (uint32_t)__popcll(m[i]);
+                }
+            }
+        }
+    }
+
+    if (gray_out.base && y < height)
+        *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
+            *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4 + 4]);
+
+    // ---- 4. Gaussian: row sums of tile rows 1 .. 22, then the column pass
     if (blur.base) {
-        for (int t = threadIdx.x; t < FE_GROWS * 32; t += FE_THREADS) {
-            const int tr = t >> 5, tg = t & 31;
-            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[tr * FE_GPITCH + tg * 4]);
+        for (int t = tid; t < FE_HROWS * 32; t += FE_THREADS) {
+            const int hr = t >> 5, tg = t & 31;
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[(hr + 1) * FE_PITCH + tg * 4]);
             const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
             uint2 o;
             o.x = hsum7<0>(d0, d1, d2) | (hsum7<1>(d0, d1, d2) << 16);
             o.y = hsum7<2>(d0, d1, d2) | (hsum7<3>(d0, d1, d2) << 16);
-            *reinterpret_cast<uint2 *>(&s_hsum[tr * FE_TW + tg * 4]) = o;
+            *reinterpret_cast<uint2 *>(&s_hsum[hr * FE_TW + tg * 4]) = o;
         }
-    }
-
-    // seven row windows around this thread's four pixels
-    uint32_t w[7][3];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-        const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[(gy + r) * FE_GPITCH + gx * 4]);
-        w[r][0] = rw[0]; w[r][1] = rw[1]; w[r][2] = rw[2];
-    }
-
-    if (gray_out.base && y < height) {
-        // centre row window holds tile columns 4gx .. 4gx+11; pixels are bytes 4..7
-        *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
-            w[3][1];
-    }
-
-    if (score.base) {
-        uint32_t s4 = 0;
-        const bool row_ok = y >= 3 && y < height - 3;
-        if (row_ok) {
-            const uint32_t s0 = fast_pixel<0>(w, thr), s1 = fast_pixel<1>(w, thr);
-            const uint32_t s2 = fast_pixel<2>(w, thr), s3 = fast_pixel<3>(w, thr);
-            s4 = (x + 0 >= 3 && x + 0 < width - 3 ? s0 : 0u) | ((x + 1 >= 3 && x + 1 < width - 3 ? s1 : 0u) << 8) |
-                 ((x + 2 >= 3 && x + 2 < width - 3 ? s2 : 0u) << 16) |
-                 ((x + 3 >= 3 && x + 3 < width - 3 ? s3 : 0u) << 24);
-        }
-        // planes are padded to whole tiles, so this store is always in bounds
-        *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) = s4;
-    }
-
-    if (blur.base) {
         __syncthreads();
         uint32_t acc[4] = {0, 0, 0, 0};
         const uint32_t kq[7] = {18, 34, 49, 55, 49, 34, 18};
@@ -253,115 +402,20 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
 
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
                      int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
-                     int batch, GrayCoeffs c, hipStream_t s)
+                     uint32_t *cand, uint32_t *cand_count, int cand_cap, int batch, GrayCoeffs c,
+                     hipStream_t s)
 {
     dim3 grid((width + FE_TW - 1) / FE_TW, (height + FE_TH - 1) / FE_TH, batch);
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c);
-}
-
-// ------------------------------------------------------------ NMS + emit
-
-// Thread = four adjacent score bytes.  A corner survives when its score is
-// strictly greater than all eight neighbours (cv::FAST with
-// nonmaxSuppression=true, reference src/feature_detector.cpp:59).  Survivors
-// are compacted with wave ballots and an LDS prefix over the block's waves,
-// so each 256x16-pixel block issues a single global atomic.
-constexpr int NMS_THREADS = 1024;
-constexpr int NMS_ROWS = NMS_THREADS / 64;
-
-__global__ __launch_bounds__(NMS_THREADS) void k_nms_emit(PlaneBatch score, int width, int height,
-                                                          uint32_t *__restrict__ cand,
-                                                          uint32_t *__restrict__ cand_count, int cand_cap)
-{
-    __shared__ uint32_t s_wave[NMS_ROWS];
-    __shared__ uint32_t s_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int gx = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * NMS_ROWS + wave;
-    const int x = gx * 4;
-    const int f = blockIdx.z;
-    const uint8_t *plane = score.base + f * score.plane_stride;
-    const int pitch = score.pitch;
-
-    uint32_t flags = 0;  // bit i: pixel x+i survives
-    uint32_t mid = 0;
-    const bool in = (y >= 3 && y < height - 3 && x < width);
-    if (in) mid = *reinterpret_cast<const uint32_t *>(plane + (size_t)y * pitch + x);
-    if (mid) {
-        // 3 rows x 6 bytes (x-1 .. x+4) as 64-bit windows
-        uint64_t rw[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const uint8_t *row = plane + (size_t)(y - 1 + r) * pitch;
-            const uint32_t m = *reinterpret_cast<const uint32_t *>(row + x);
-            const uint32_t l = x > 0 ? row[x - 1] : 0u;
-            const uint32_t rr = x + 4 < pitch ? row[x + 4] : 0u;
-            rw[r] = (uint64_t)l | ((uint64_t)m << 8) | ((uint64_t)rr << 40);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t sc = (uint32_t)(rw[1] >> (8 * (i + 1))) & 255u;
-            if (!sc) continue;
-            bool keep = true;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    if (r == 1 && d == 1) continue;
-                    keep = keep && sc > ((uint32_t)(rw[r] >> (8 * (i + d))) & 255u);
-                }
-            }
-            if (keep) flags |= 1u << i;
-        }
-    }
-
-    uint64_t m[4];
-    uint32_t total = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        m[i] = __ballot((flags >> i) & 1u);
-        total += (uint32_t)__popcll(m[i]);
-    }
-    if (lane == 0) s_wave[wave] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int w = 0; w < NMS_ROWS; w++) tot += s_wave[w];
-        s_base = tot ? atomicAdd(&cand_count[f], tot) : 0u;
-    }
-    __syncthreads();
-    if (total == 0) return;
-    uint32_t off = s_base;
-    for (int w = 0; w < wave; w++) off += s_wave[w];
-    const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if ((flags >> i) & 1u) {
-            const uint32_t slot = off + __popcll(m[i] & lt);
-            const uint32_t sc = (mid >> (8 * i)) & 255u;
-            if (slot < (uint32_t)cand_cap)
-                cand[(size_t)f * cand_cap + slot] = ((255u - sc) << 24) | (uint32_t)(y * width + x + i);
-        }
-        off += __popcll(m[i]);
-    }
-}
-
-void launch_nms_emit(PlaneBatch score, int width, int height, uint32_t *cand, uint32_t *cand_count,
-                     int cand_cap, int batch, hipStream_t s)
-{
-    dim3 grid((width + 255) / 256, (height + NMS_ROWS - 1) / NMS_ROWS, batch);
-    hipLaunchKernelGGL(k_nms_emit, grid, dim3(NMS_THREADS), 0, s, score, width, height, cand, cand_count,
-                       cand_cap);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
 }
 
 // ---------------------------------------------------------------- select

@@ -241,7 +241,7 @@ int vo_fast_score(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int 
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = stage_image(c, gray, w, h, stride))) return rc;
     launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, c->plane(c->d_score),
-                    PlaneBatch{nullptr, 0, 0}, threshold, 1, c->gc, c->stream);
+                    PlaneBatch{nullptr, 0, 0}, threshold, nullptr, nullptr, 0, 1, c->gc, c->stream);
     HIP_TRY(c, hipMemcpy2DAsync(score, score_stride, c->d_score, c->pitch, w, h, hipMemcpyDefault, c->stream));
     return finish(c, "vo_fast_score");
 }
@@ -254,7 +254,7 @@ int vo_blur7(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, uint8_t *
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = stage_image(c, gray, w, h, stride))) return rc;
     launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
-                    c->plane(c->d_blur), 0, 1, c->gc, c->stream);
+                    c->plane(c->d_blur), 0, nullptr, nullptr, 0, 1, c->gc, c->stream);
     HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->d_blur, c->pitch, w, h, hipMemcpyDefault, c->stream));
     return finish(c, "vo_blur7");
 }
@@ -395,26 +395,25 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
     (void)hipMemsetAsync(d_cand_count, 0, sizeof(uint32_t) * batch, stream);
     mark(0);
     launch_frontend(src, w, h, src_stride, src_frame_stride, channels, PlaneBatch{nullptr, 0, 0},
-                    plane(d_score), plane(d_blur), fast_threshold, batch, gc, stream);
+                    PlaneBatch{nullptr, 0, 0}, plane(d_blur), fast_threshold, d_cand, d_cand_count, cand_cap, batch,
+                    gc, stream);
     mark(1);
-    launch_nms_emit(plane(d_score), w, h, d_cand, d_cand_count, cand_cap, batch, stream);
-    mark(2);
     launch_select(d_cand, d_cand_count, cand_cap, w, h, max_features, kFBorder,
                   d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot, batch, stream);
-    mark(3);
+    mark(2);
     launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
                  d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
 }
 
 void vo_ctx::enqueue_match(int pairs, float ratio, FRansacParams prm)
 {
-    mark(4);
+    mark(3);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
                 pairs, stream);
-    mark(5);
+    mark(4);
     launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio, d_knn, d_good,
                           d_ngood, pairs, stream);
-    mark(6);
+    mark(5);
     launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
                     stream);
 }

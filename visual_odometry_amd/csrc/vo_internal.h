@@ -34,18 +34,17 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride,
                  size_t src_frame_stride, int channels, PlaneBatch dst,
                  int batch, GrayCoeffs c, hipStream_t s);
 
-// Fused tile kernel: (optional BGR[A]->gray) + FAST-9/16 corner score map +
-// 7x7 fixed-point Gaussian.  Any of gray_out/score/blur may have base == 0.
+// Fused tile kernel: (optional BGR[A]->gray) + FAST-9/16 with 3x3 strict
+// non-max suppression + 7x7 fixed-point Gaussian.  Corners that survive the
+// suppression are appended to cand[frame*cand_cap ...] as keys
+// ((255-score) << 24) | (y*width + x) (cand_count must be zero on entry).
+// Any of gray_out/score/blur may have base == 0, cand may be null; `score`
+// receives the per-pixel score map (diagnostic).
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
                      size_t src_frame_stride, int channels, PlaneBatch gray_out,
                      PlaneBatch score, PlaneBatch blur, int threshold,
+                     uint32_t *cand, uint32_t *cand_count, int cand_cap,
                      int batch, GrayCoeffs c, hipStream_t s);
-
-// 3x3 strict non-max suppression over the score map; survivors are appended
-// to cand[frame*cand_cap ...] as keys ((255-score) << 24) | (y*width + x).
-void launch_nms_emit(PlaneBatch score, int width, int height, uint32_t *cand,
-                     uint32_t *cand_count, int cand_cap, int batch,
-                     hipStream_t s);
 
 // Keep the max_features best keys per frame (all of them, in raster order,
 // when there are not more than max_features), drop keypoints closer than
