@@ -193,6 +193,15 @@ typedef struct {
 int vo_batch_configure(vo_ctx *ctx, const vo_batch_cfg *cfg);
 /* the next frame of every stream becomes a first frame */
 int vo_batch_reset(vo_ctx *ctx);
+/* Replace the camera intrinsics (and enable the pose stage) without touching
+ * the streams' state; CameraParams is an argument of every processFrame call
+ * (reference src/frame_processor.cpp:18-24). */
+int vo_batch_set_camera(vo_ctx *ctx, double fx, double fy, double cx, double cy);
+/* FrameProcessor::setPreviousFrame(frame, depth, features): make `features`
+ * the previous frame of `stream`; its track ages restart at 0.
+ * reference src/frame_processor.cpp:220-228 */
+int vo_batch_set_previous(vo_ctx *ctx, int stream, const vo_kp *kps,
+                          const uint8_t *desc, int n);
 /* Enqueue one batch. frames: batch x height x row_stride bytes, consecutive
  * frames frame_stride bytes apart; depth (may be NULL): float32 mm, strides
  * in elements.  Device pointers are read in place; host pointers are copied

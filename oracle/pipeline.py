@@ -20,7 +20,29 @@ class OracleStream:
         self.prev = None
         self.prev_ages = np.zeros(0, np.int32)
 
-    def process(self, frame: np.ndarray, depth: np.ndarray | None = None) -> dict:
+    @staticmethod
+    def imu_filter(valid, pts3, camera, R, t, angular_rate):
+        """IMU-guided feature filter (reference src/frame_processor.cpp:99-173)."""
+        fx, fy, cx, cy = camera
+        rv = O.rodrigues(np.asarray(R, np.float64))
+        Rm = O.rodrigues(rv)
+        P = pts3.astype(np.float64) @ Rm.T + np.asarray(t, np.float64).reshape(3)
+        z = np.where(P[:, 2] != 0, 1.0 / P[:, 2], 1.0)
+        u = (P[:, 0] * z * fx + cx).astype(np.float32)
+        v = (P[:, 1] * z * fy + cy).astype(np.float32)
+        dx = (u - valid["px"]).astype(np.float64)
+        dy = (v - valid["py"]).astype(np.float64)
+        err = np.sqrt(dx * dx + dy * dy)
+        n = len(err)
+        thr = 10.0 + angular_rate * 5.0
+        min_retain = min(max(100, int(n * 0.6)), n)
+        keep = np.flatnonzero(err <= thr)
+        if len(keep) < min_retain:
+            order = sorted(range(n), key=lambda i: (err[i], i))
+            keep = np.array(sorted(order[:min_retain]), np.int64)
+        return keep
+
+    def process(self, frame: np.ndarray, depth: np.ndarray | None = None, imu=None) -> dict:
         gray = frame if frame.ndim == 2 else O.gray(frame)
         kps, desc = O.detect(gray, self.max_features, self.fast_threshold)
         out = {"kps": kps, "desc": desc, "matches": np.zeros(0, O.MATCH_DTYPE), "n_ratio": 0,
@@ -40,6 +62,10 @@ class OracleStream:
                 fx, fy, cx, cy = self.camera
                 valid, pts3 = O.backproject(tracked, depth, fx, fy, cx, cy)
                 if len(pts3):
+                    if imu is not None and len(pts3) >= 100:
+                        keep = self.imu_filter(valid, pts3, self.camera, *imu)
+                        if len(keep) < len(pts3):
+                            valid, pts3 = valid[keep], pts3[keep]
                     out["valid"], out["pts3"] = valid, pts3
                     if len(pts3) >= 4:
                         img = np.stack([valid["px"], valid["py"]], 1)

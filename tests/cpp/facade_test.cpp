@@ -1,0 +1,93 @@
+// Drives the C++ facades (FeatureDetector / FeatureMatcher / FrameProcessor)
+// exactly as vo_node does (reference src/vo_node.cpp:79-80,170-173,681) over a
+// raw frame dump written by tests/test_gpu_facade.py, and prints the results
+// for the Python side to compare with the oracle.
+//
+// usage: facade_test <dump> <width> <height> <channels> <n_frames> <fx> <fy> <cx> <cy> [imu_tx_mm]
+// dump layout: n_frames x (H*W*C bytes), then n_frames x (H*W float32 depth)
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "visual_odometry/frame_processor.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 10) return 2;
+    const char *path = argv[1];
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), c = std::atoi(argv[4]), n = std::atoi(argv[5]);
+    vo::CameraParams cam;
+    cam.fx = std::atof(argv[6]); cam.fy = std::atof(argv[7]); cam.cx = std::atof(argv[8]); cam.cy = std::atof(argv[9]);
+    cam.width = w; cam.height = h;
+    const bool use_imu = argc > 10;
+    const double imu_tx = use_imu ? std::atof(argv[10]) : 0.0;
+
+    std::vector<uint8_t> frames((size_t)n * w * h * c);
+    std::vector<float> depth((size_t)n * w * h);
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return 3;
+    if (std::fread(frames.data(), 1, frames.size(), f) != frames.size()) return 4;
+    if (std::fread(depth.data(), sizeof(float), depth.size(), f) != depth.size()) return 4;
+    std::fclose(f);
+
+    auto detector = std::make_shared<vo::FeatureDetector>();
+    auto matcher = std::make_shared<vo::FeatureMatcher>();
+    detector->setMaxFeatures(2000);
+    detector->setScaleFactor(1.2f);
+    detector->setNLevels(8);
+    detector->setVisualizationType("rich");
+    vo::FrameProcessor fp(detector, matcher);
+
+    vo::Features prev_feat;
+    for (int i = 0; i < n; i++) {
+        cv::Mat rgb(h, w, CV_MAKETYPE(CV_8U, c), frames.data() + (size_t)i * w * h * c);
+        cv::Mat dep(h, w, CV_32FC1, depth.data() + (size_t)i * w * h);
+        vo::ImuPredictedPose imu;
+        if (use_imu && i > 0) {
+            imu.valid = true;
+            imu.R = cv::Mat::eye(3, 3, CV_64F);
+            imu.t = cv::Mat::zeros(3, 1, CV_64F);
+            imu.t.at<double>(0, 0) = imu_tx;
+            imu.angular_rate = 0.0;
+        }
+        auto r = fp.processFrame(rgb, dep, cam, i == 0, true, imu);
+        std::printf("frame %d kp %zu matches %zu p3d %zu pnp %d inl %d tot %d", i, r.features.keypoints.size(),
+                    r.matches.size(), r.matches.prev_points_3d.size(), (int)r.pnp_success, r.pnp_inliers,
+                    r.pnp_total_matches);
+        if (r.pnp_success) {
+            std::printf(" R");
+            for (int k = 0; k < 9; k++) std::printf(" %.17g", r.R.at<double>(k / 3, k % 3));
+            std::printf(" t %.17g %.17g %.17g", r.t.at<double>(0, 0), r.t.at<double>(1, 0), r.t.at<double>(2, 0));
+        }
+        std::printf("\n");
+        // the standalone operators, as vo_node's components would use them
+        if (i == 1) {
+            cv::Mat bgr(h, w, CV_8UC3);
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++)
+                    for (int k = 0; k < 3; k++) bgr.ptr<uint8_t>(y)[3 * x + k] = rgb.ptr<uint8_t>(y)[c * x + k];
+            vo::Features cur = detector->detectFeatures(bgr);  // defaults 1000 / 20
+            vo::FeatureMatches m = matcher->match(prev_feat, cur, cv::Mat(), cv::Mat());
+            std::printf("ops kp %zu desc_rows %d matches %zu\n", cur.keypoints.size(), cur.descriptors.rows, m.size());
+        }
+        if (i == 0) {
+            cv::Mat bgr(h, w, CV_8UC3);
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++)
+                    for (int k = 0; k < 3; k++) bgr.ptr<uint8_t>(y)[3 * x + k] = rgb.ptr<uint8_t>(y)[c * x + k];
+            prev_feat = detector->detectFeatures(bgr);
+        }
+    }
+    // error convention: detectFeatures swallows, processFrame throws
+    vo::Features bad = detector->detectFeatures(cv::Mat());
+    std::printf("empty_detect kp %zu\n", bad.keypoints.size());
+    try {
+        cv::Mat gray(h, w, CV_8UC1, frames.data());
+        fp.processFrame(gray, cv::Mat(), cam);
+        std::printf("gray_process no_throw\n");
+    } catch (const std::exception &e) {
+        std::printf("gray_process threw\n");
+    }
+    return 0;
+}

@@ -74,6 +74,8 @@ EXPORTS = {
                                       C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     "vo_batch_configure": (C.c_int, [_P, C.POINTER(VoBatchCfg)]),
     "vo_batch_reset": (C.c_int, [_P]),
+    "vo_batch_set_camera": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "vo_batch_set_previous": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "vo_batch_submit": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _P, C.c_int, C.c_size_t]),
     "vo_batch_wait": (C.c_int, [_P, _P]),
     "vo_batch_get_features": (C.c_int, [_P, C.c_int, _P, _P, _P]),

@@ -190,7 +190,10 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
                               depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
                               c->d_bpinfo, B, c->stream);
     c->mark(8);
-    if (b.enable_pose && dsrc)
+    if (!(b.enable_pose && dsrc)) {
+        HIP_TRY(c, hipMemsetAsync(c->d_pose, 0, sizeof(int) * 4 * B, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_rt, 0, sizeof(double) * 6 * B, c->stream));
+    } else
         launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
                           b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
                           c->d_rt, B, c->stream);
@@ -205,6 +208,42 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));
     c->submitted = true;
     c->streams_started = true;
+    return VO_OK;
+}
+
+int vo_batch_set_camera(vo_ctx *c, double fx, double fy, double cx, double cy)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured) return bfail(c, VO_ERR_STATE, "vo_batch_set_camera: configure first");
+    if (c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_set_camera: a batch is in flight");
+    if (!(fx > 0 && fy > 0)) return bfail(c, VO_ERR_ARG, "vo_batch_set_camera: fx, fy must be positive");
+    c->bcfg.fx = fx; c->bcfg.fy = fy; c->bcfg.cx = cx; c->bcfg.cy = cy;
+    c->bcfg.enable_pose = 1;
+    return VO_OK;
+}
+
+int vo_batch_set_previous(vo_ctx *c, int stream, const vo_kp *kps, const uint8_t *desc, int n)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured || c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_set_previous: bad state");
+    if (stream < 0 || stream >= c->bcfg.n_streams || n < 0 || n > c->cfg.max_features || (n && (!kps || !desc)))
+        return bfail(c, VO_ERR_ARG, "vo_batch_set_previous: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int S = c->bcfg.n_streams, F = c->bcfg.frames_per_stream, B = S * F;
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->d_kps + (size_t)stream * c->kp_stride, kps, sizeof(vo_kp) * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(c->d_desc + (size_t)stream * c->kp_stride * 32, desc, (size_t)32 * n, hipMemcpyDefault));
+    }
+    HIP_TRY(c, hipMemcpy(c->d_nkp + stream, &n, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_ages + (size_t)stream * c->kp_stride, 0, sizeof(int) * c->kp_stride));
+    // link every stream's first frame to its carry slot (empty carry slots hold 0 keypoints)
+    std::vector<int> q(B), hp(B, 1);
+    for (int s = 0; s < S; s++)
+        for (int f = 0; f < F; f++) q[s * F + f] = f > 0 ? S + s * F + f - 1 : s;
+    HIP_TRY(c, hipMemcpy(c->d_qslot, q.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_has_prev, hp.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+    c->streams_started = true;
+    c->first_pairs_linked = true;
     return VO_OK;
 }
 
