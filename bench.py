@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--streams", type=int, default=16, help="independent camera streams per GPU")
     ap.add_argument("--frames", type=int, default=16, help="consecutive frames per stream per step (even)")
     ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="vo_ctx objects per GPU (each owns streams/contexts camera streams and one HIP "
+                         "stream); batches of different contexts overlap on the GPU")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames timed for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -86,21 +89,31 @@ def main():
 
     from visual_odometry_amd import capi
 
-    S, F = args.streams, args.frames
-    B = S * F
+    NC = max(1, args.contexts)
+    assert args.streams % NC == 0, "--streams must be a multiple of --contexts"
+    S, F = args.streams // NC, args.frames   # streams per context
+    Bc = S * F                               # frames per context per step
+    B = Bc * NC                              # frames per step per GPU
     cam, frames_h, depth_h = build_inputs(S, F, seed=2000 + rank)
-    frames_d = torch.from_numpy(frames_h).cuda()
-    depth_d = torch.from_numpy(depth_h).cuda()
     H, W, C = cam.height, cam.width, 4
     K = (cam.fx, cam.fy, cam.cx, cam.cy)
-
-    ctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=args.features, max_batch=B)
-    ctx.batch_configure(W, H, C, n_streams=S, frames_per_stream=F, max_features=args.features,
-                        fast_threshold=20, camera=K)
+    # every context owns its own copy of the input frames in HBM
+    frames_d = [torch.from_numpy(frames_h).cuda() for _ in range(NC)]
+    depth_d = [torch.from_numpy(depth_h).cuda() for _ in range(NC)]
+    ctxs = []
+    for _ in range(NC):
+        c = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=args.features, max_batch=Bc)
+        c.batch_configure(W, H, C, n_streams=S, frames_per_stream=F, max_features=args.features,
+                          fast_threshold=20, camera=K)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     def step():
-        ctx.batch_submit_ptr(frames_d.data_ptr(), W * C, W * C * H, depth_d.data_ptr(), W, W * H)
-        return ctx.batch_wait()
+        # all contexts in flight at once: their kernels interleave on the GPU
+        for c, fd, dd in zip(ctxs, frames_d, depth_d):
+            c.batch_submit_ptr(fd.data_ptr(), W * C, W * C * H, dd.data_ptr(), W, W * H)
+        out = [c.batch_wait() for c in ctxs]
+        return np.concatenate(out)
 
     for _ in range(args.warmup):
         res = step()
@@ -122,11 +135,13 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, dist, "cuda")
 
     # per-kernel durations with HIP events on the library's own stream
+    # (context 0 alone, so that one launch's duration is not stretched by another context's kernels)
     ctx.batch_set_timing(True)
     acc = {}
     reps = 5
     for _ in range(reps):
-        step()
+        ctx.batch_submit_ptr(frames_d[0].data_ptr(), W * C, W * C * H, depth_d[0].data_ptr(), W, W * H)
+        ctx.batch_wait()
         for k, v in ctx.batch_timing().items():
             acc[k] = acc.get(k, 0.0) + v / reps
     ctx.batch_set_timing(False)
@@ -136,9 +151,9 @@ def main():
         cand_bytes = 4.0
         # algorithmic work per launch (one launch covers the whole batch of B frames)
         work = {
-            "frontend_fast_nms_blur": ("hbm", B * W * H * (C + 1) / 1e9, HBM_PEAK_GBS, "GB/s"),
-            "brief": ("hbm", B * n_kp * (512 + 32) / 1e9, HBM_PEAK_GBS, "GB/s"),
-            "knn2": ("valu", B * n_kp * n_kp * 16 / 1e9, VALU_PEAK_GLOPS, "Glane-op/s"),
+            "frontend_fast_nms_blur": ("hbm", Bc * W * H * (C + 1) / 1e9, HBM_PEAK_GBS, "GB/s"),
+            "brief": ("hbm", Bc * n_kp * (512 + 32) / 1e9, HBM_PEAK_GBS, "GB/s"),
+            "knn2": ("valu", Bc * n_kp * n_kp * 16 / 1e9, VALU_PEAK_GLOPS, "Glane-op/s"),
         }
         dominant = max(acc, key=acc.get)
         roof = {"kernel": dominant, "ms_per_launch": acc[dominant], "bound": None, "achieved": None,
@@ -156,7 +171,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (image, match), f64 (RANSAC)", "data": "synthetic",
             "config": {"workload": "hd720_bgra_mono_stream_2000kp_modeA_ratio_Fransac_pnp",
-                       "streams_per_gpu": S, "frames_per_stream_per_step": F, "frames_per_step": B,
+                       "streams_per_gpu": S * NC, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
+                       "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,
                        "parallelism": "independent streams, one process per GPU, no collective"},
             "roofline": roof,
@@ -172,7 +188,8 @@ def main():
                                    "sample": f"{args.cpu_frames} HD720 frames of the same stream, "
                                              "oracle C pipeline, 1 thread"}
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

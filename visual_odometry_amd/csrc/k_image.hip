@@ -163,24 +163,101 @@ __device__ __forceinline__ bool nms_px(const uint32_t (&a)[3], const uint32_t (&
            s > win_byte<4 + I>(b[0], b[1], b[2]) && s > win_byte<5 + I>(b[0], b[1], b[2]);
 }
 
-// One block = one 128x16 tile of one frame.
-//   0. stage the tile plus a 4-px apron in LDS as 8-bit gray (BGR/BGRA are
-//      converted on the way in);
+constexpr int FE_TASKS = FE_GROWS * (FE_PITCH / 4);  // 4-pixel staging tasks per tile
+constexpr int FE_TPT = (FE_TASKS + FE_THREADS - 1) / FE_THREADS;  // tasks per thread
+
+// Pixels of one staging task (4 horizontally adjacent pixels), still in the
+// layout they were loaded in.
+template <int CN>
+struct FePre {
+    uint32_t v[CN == 3 ? 12 : 4];
+};
+
+struct FeTile {
+    int frame, x0, y0;
+    bool inside;  // the tile and its apron lie inside the image: no reflection
+};
+
+// issue the global loads of staging task i of a tile (no wait)
+template <int CN>
+__device__ __forceinline__ void fe_issue(FePre<CN> &p, const uint8_t *img, int src_stride, int width, int height,
+                                         const FeTile &t, int i, bool aligned)
+{
+    const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
+    const int yb = t.y0 - 4 + tr, xb = t.x0 - 4 + tq * 4;
+    if (t.inside && aligned) {
+        const uint8_t *row = img + (size_t)yb * src_stride;
+        if (CN == 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
+            p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
+        } else if (CN == 1) {
+            p.v[0] = *reinterpret_cast<const uint32_t *>(row + xb);
+        } else {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (size_t)xb * 3);
+            p.v[0] = q[0]; p.v[1] = q[1]; p.v[2] = q[2];
+        }
+    } else {
+        const uint8_t *row = img + (size_t)reflect101(yb, height) * src_stride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int xx = reflect101(xb + j, width);
+            if (CN == 4) p.v[j] = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
+            else if (CN == 1) p.v[j] = row[xx];
+            else { p.v[3 * j] = row[xx * 3]; p.v[3 * j + 1] = row[xx * 3 + 1]; p.v[3 * j + 2] = row[xx * 3 + 2]; }
+        }
+    }
+}
+
+// four gray bytes of a loaded task
+template <int CN>
+__device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, GrayCoeffs c)
+{
+    uint32_t out = 0;
+    if (CN == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            out |= gray_of(p.v[j] & 255u, (p.v[j] >> 8) & 255u, (p.v[j] >> 16) & 255u, c) << (8 * j);
+    } else if (CN == 1) {
+        if (packed) out = p.v[0];
+        else out = p.v[0] | (p.v[1] << 8) | (p.v[2] << 16) | (p.v[3] << 24);
+    } else if (packed) {
+        // 12 bytes B0 G0 R0 B1 ... R3 in three dwords
+        const uint32_t d0 = p.v[0], d1 = p.v[1], d2 = p.v[2];
+        out = gray_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, c) |
+              (gray_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, c) << 8) |
+              (gray_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, c) << 16) |
+              (gray_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, c) << 24);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) out |= gray_of(p.v[3 * j], p.v[3 * j + 1], p.v[3 * j + 2], c) << (8 * j);
+    }
+    return out;
+}
+
+// One block = one 128x16 tile of one frame:
+//   0. the tile plus a 4-px apron is staged in LDS as 8-bit gray (BGR/BGRA are
+//      converted on the way in; 16-B vector loads, all issued before first use);
 //   1. cheap FAST pre-test on the tile and its 1-px rim; survivors are queued
 //      in LDS (wave ballot + one LDS atomic per wave);
 //   2. the queue is processed densely: full FAST-9/16 score into an LDS score tile;
 //   3. 3x3 strict non-max suppression on the tile (cv::FAST, nonmaxSuppression
 //      = true), survivors appended to the frame's candidate list as keys
-//      ((255-score) << 24) | raster index, one global atomic per block;
+//      ((255-score) << 24) | raster index, one global atomic per block and tile;
 //   4. 7x7 Gaussian through 16-bit row sums.
 // tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
+//
+// Tile order is XCD-aware: blocks b and b+8 share an XCD (and its L2), so XCD
+// x = b % 8 walks down whole tile columns (frame*tiles_x + tx) congruent to x
+// mod 8; vertically adjacent tiles, which share 8 of their 24 staged rows, are
+// then processed by the same L2 at about the same time.
 template <int CN>
 __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
                                                          int height, int src_stride,
                                                          size_t src_frame_stride, PlaneBatch gray_out,
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
-                                                         uint32_t *__restrict__ cand_count, int cand_cap)
+                                                         uint32_t *__restrict__ cand_count, int cand_cap,
+                                                         int batch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
@@ -190,57 +267,50 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     __shared__ uint32_t s_wave[FE_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * FE_TW, y0 = blockIdx.y * FE_TH;
-    const int f = blockIdx.z;
-    const uint8_t *img = src + f * src_frame_stride;
+    const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int ncols = batch * tiles_x;
+    const int my_cols = (ncols - xcd + 7) / 8;
+    const int count = my_cols * tiles_y;  // tiles this XCD's blocks share
+    // rows 16-B (BGRA) / 4-B (gray, BGR) aligned: vector loads allowed
+    const bool aligned = CN == 4 ? ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 15) == 0)
+                                 : ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 3) == 0);
 
-    // ---- 0. stage
-    const bool inside = x0 >= 4 && x0 + FE_PITCH - 4 <= width && y0 >= 4 && y0 + FE_GROWS - 4 <= height;
-    for (int i = tid; i < FE_GROWS * (FE_PITCH / 4); i += FE_THREADS) {
-        const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
-        uint32_t packed = 0;
-        if (inside) {
-            const uint8_t *row = img + (size_t)(y0 - 4 + tr) * src_stride;
-            const int xb = x0 - 4 + tq * 4;
-            if (CN == 1) {
+    auto decode = [&](int k) {
+        FeTile t;
+        const int col = (k / tiles_y) * 8 + xcd, ty = k - (k / tiles_y) * tiles_y;
+        t.frame = col / tiles_x;
+        t.x0 = (col - t.frame * tiles_x) * FE_TW;
+        t.y0 = ty * FE_TH;
+        t.inside = t.x0 >= 4 && t.x0 + FE_PITCH - 4 <= width && t.y0 >= 4 && t.y0 + FE_GROWS - 4 <= height;
+        return t;
+    };
+
+    const int k = j0;
+    if (k >= count) return;
+    const FeTile tile = decode(k);
+    const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
+
+    // ---- 0. stage: all global loads of the thread are issued before the first use
+    {
+        FePre<CN> pre[FE_TPT];
+        const uint8_t *img = src + f * src_frame_stride;
 #pragma unroll
-                for (int j = 0; j < 4; j++) packed |= (uint32_t)row[xb + j] << (8 * j);
-            } else if (CN == 4) {
+        for (int u = 0; u < FE_TPT; u++)
+            if (tid + u * FE_THREADS < FE_TASKS)
+                fe_issue<CN>(pre[u], img, src_stride, width, height, tile, tid + u * FE_THREADS, aligned);
+        for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
+        if (tid == 0) s_qcount = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)(xb + j) * 4);
-                    packed |= gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c) << (8 * j);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint8_t *p = row + (size_t)(xb + j) * 3;
-                    packed |= gray_of(p[0], p[1], p[2], c) << (8 * j);
-                }
-            }
-        } else {
-            const int yy = reflect101(y0 - 4 + tr, height);
-            const uint8_t *row = img + (size_t)yy * src_stride;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int xx = reflect101(x0 - 4 + tq * 4 + j, width);
-                uint32_t g;
-                if (CN == 1) {
-                    g = row[xx];
-                } else if (CN == 4) {
-                    const uint32_t px = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
-                    g = gray_of(px & 255u, (px >> 8) & 255u, (px >> 16) & 255u, c);
-                } else {
-                    const uint8_t *p = row + (size_t)xx * 3;
-                    g = gray_of(p[0], p[1], p[2], c);
-                }
-                packed |= g << (8 * j);
+        for (int u = 0; u < FE_TPT; u++) {
+            const int i = tid + u * FE_THREADS;
+            if (i < FE_TASKS) {
+                const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
+                *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) =
+                    fe_gray4<CN>(pre[u], tile.inside && aligned, c);
             }
         }
-        *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) = packed;
     }
-    for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
-    if (tid == 0) s_qcount = 0;
     __syncthreads();
 
     const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
@@ -405,17 +475,21 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
                      uint32_t *cand, uint32_t *cand_count, int cand_cap, int batch, GrayCoeffs c,
                      hipStream_t s)
 {
-    dim3 grid((width + FE_TW - 1) / FE_TW, (height + FE_TH - 1) / FE_TH, batch);
+    // block b serves XCD group b % 8, which owns the tile columns congruent to
+    // b % 8; the grid holds the largest group's tile count for every group
+    const int ncols = ((width + FE_TW - 1) / FE_TW) * batch, tiles_y = (height + FE_TH - 1) / FE_TH;
+    const int blocks = 8 * ((ncols + 7) / 8) * tiles_y;
+    dim3 grid(blocks);
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
 }
 
 // ---------------------------------------------------------------- select
