@@ -5,7 +5,7 @@
 
 namespace vo {
 
-constexpr int KNN_THREADS = 256;
+constexpr int KNN_THREADS = 128;
 constexpr int KNN_QPL = 2;                           // queries per lane
 constexpr int KNN_QPB = KNN_THREADS * KNN_QPL;       // queries per block
 constexpr int KNN_TILE = 128;                        // train descriptors per LDS tile
@@ -41,16 +41,14 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         k0[i] = k1[i] = 0xffffffffu;
     }
 
-    // this block's share of the train set, in whole tiles
-    const int tiles = (nt + KNN_TILE - 1) / KNN_TILE;
-    const int per = (tiles + kKnnSplits - 1) / kKnnSplits;
-    const int tile_lo = split * per, tile_hi = min(tile_lo + per, tiles);
+    // this block's share of the train set: an even cut of the descriptors
+    const int j_lo = (int)(((long long)nt * split) / kKnnSplits);
+    const int j_hi = (int)(((long long)nt * (split + 1)) / kKnnSplits);
 
-    for (int tile = tile_lo; tile < tile_hi; tile++) {
-        const int j0 = tile * KNN_TILE;
-        const int jn = min(KNN_TILE, nt - j0);
+    for (int j0 = j_lo; j0 < j_hi; j0 += KNN_TILE) {
+        const int jn = min(KNN_TILE, j_hi - j0);
         __syncthreads();
-        if ((int)threadIdx.x < jn * 2) s_tile[threadIdx.x] = td[2 * j0 + threadIdx.x];
+        for (int i = threadIdx.x; i < jn * 2; i += KNN_THREADS) s_tile[i] = td[2 * j0 + i];
         __syncthreads();
         for (int j = 0; j < jn; j++) {
             const uint4 ta = s_tile[2 * j], tb = s_tile[2 * j + 1];  // wave-uniform: LDS broadcast
@@ -124,10 +122,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
             uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
 #pragma unroll
             for (int s = 0; s < kKnnSplits; s++) {
-                // splits that own no tile leave their slot unwritten: recompute ownership
-                const int tiles = (nt + KNN_TILE - 1) / KNN_TILE;
-                const int per = (tiles + kKnnSplits - 1) / kKnnSplits;
-                if (s * per >= tiles) continue;
+                // every split writes its slot (0xffffffff keys when its share is empty)
                 const uint2 p = partial[((size_t)pair * kKnnSplits + s) * kp_stride + q];
                 uint32_t key = p.x;
                 uint32_t n0 = min(k0, key);
