@@ -136,8 +136,32 @@ int vo_find_fundamental_ransac(vo_ctx *ctx, const float *p1, const float *p2,
  * survivors, or no RANSAC model) returns VO_OK with *n_out = 0.
  * reference src/feature_matcher.cpp:15-104 */
 int vo_match_features(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev_desc,
-             int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
-             int n_curr, float ratio, vo_match *out, int *n_out);
+                      int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
+                      int n_curr, float ratio, vo_match *out, int *n_out);
+
+/* ImageProcessor::processImage (reference src/image_processor.cpp:6-79,
+ * include/visual_odometry/image_processor.hpp:8-38).  gray = BGR2GRAY of a
+ * 3-channel frame or a copy of a 1-channel one.  With enhance != 0 also:
+ * enhanced = cv::equalizeHist(gray) when hist_eq, else gray; denoised =
+ * cv::GaussianBlur(enhanced, Size(blur_size, blur_size), sigma) when
+ * blur_size > 1 (odd, <= 31; the 8-bit fixed-point path, BORDER_REFLECT_101),
+ * else enhanced; masked = denoised with rows outside [h/4, 3h/4] zeroed.
+ * All outputs are host planes with the row stride out_stride. */
+int vo_image_process(vo_ctx *ctx, const uint8_t *src, int w, int h, int src_stride,
+                     int channels, int enhance, int hist_eq, int blur_size,
+                     double sigma, uint8_t *gray, uint8_t *enhanced,
+                     uint8_t *denoised, uint8_t *masked, int out_stride);
+
+/* The same with an optional cross-check: a ratio-test survivor (i, j) is kept
+ * only when i is also the nearest previous descriptor of j (mutual nearest
+ * neighbours, ties to the lower index).  An extension: the reference creates
+ * its matcher with crossCheck = false (src/feature_matcher.cpp:8) although
+ * its yaml declares feature_detector.matching.cross_check
+ * (config/vo_params.yaml). */
+int vo_match_features_ex(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev_desc,
+                         int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
+                         int n_curr, float ratio, int cross_check, vo_match *out,
+                         int *n_out);
 
 /* cv::solvePnPRansac(obj, img, K, dist = 0, rvec, tvec, false, iters,
  * reproj_threshold, confidence, inliers) followed by nothing else (the caller
@@ -177,6 +201,7 @@ typedef struct {
     double fx, fy, cx, cy;            /* CameraParams */
     int pnp_iters;                    /* reference 100 */
     double pnp_threshold, pnp_confidence; /* reference 8.0, 0.99 */
+    int cross_check;                  /* mutual-nearest filter after the ratio test (reference: 0) */
 } vo_batch_cfg;
 
 typedef struct {

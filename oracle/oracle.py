@@ -53,6 +53,8 @@ def lib():
                                            C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         _lib.ora_match_filter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_match_filter_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -92,6 +94,49 @@ def blur7(g: np.ndarray) -> np.ndarray:
     h, w = g.shape
     out = np.empty((h, w), np.uint8)
     lib().ora_blur7(_p(g), w, h, w, _p(out), w)
+    return out
+
+
+def equalize_hist(g: np.ndarray) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_equalize_hist(_p(g), w, h, w, _p(out), w)
+    return out
+
+
+def gaussian_taps_q8(n: int, sigma: float) -> np.ndarray:
+    taps = np.zeros(31, np.int32)
+    if not lib().ora_gaussian_taps_q8(n, C.c_double(sigma), _p(taps)):
+        raise ValueError("kernel size must be odd and in 1..31")
+    return taps[:n].copy()
+
+
+def gaussian_blur(g: np.ndarray, n: int = 3, sigma: float = 1.0) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    if not lib().ora_gaussian_blur(_p(g), w, h, w, n, C.c_double(sigma), _p(out), w):
+        raise ValueError("kernel size must be odd and in 1..31")
+    return out
+
+
+def roi_mask(g: np.ndarray) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ora_roi_mask(_p(g), w, h, w, _p(out), w)
+    return out
+
+
+def process_image(img: np.ndarray, enhance=False, blur_size=3, sigma=1.0, hist_eq=False) -> dict:
+    """ImageProcessor::processImage (reference src/image_processor.cpp:6-28)."""
+    out = {"gray": gray(img) if img.ndim == 3 and img.shape[2] == 3 else np.ascontiguousarray(img).copy()}
+    if enhance:
+        out["enhanced"] = equalize_hist(out["gray"]) if hist_eq else out["gray"].copy()
+        out["denoised"] = gaussian_blur(out["enhanced"], blur_size, sigma) if blur_size > 1 \
+            else out["enhanced"].copy()
+        out["masked"] = roi_mask(out["denoised"])
     return out
 
 
@@ -163,13 +208,13 @@ def find_fundamental_ransac(p1, p2, thr=3.0, conf=0.99, max_iters=1000):
     return bool(ok), F.reshape(3, 3), mask[:n].copy(), iters.value
 
 
-def match_filter(knn, nt, qk, tk, ratio=0.7):
+def match_filter(knn, nt, qk, tk, ratio=0.7, knn_rev=None):
     nq = len(knn)
     out = np.zeros(max(nq, 1), MATCH_DTYPE)
     mask = np.zeros(max(nq, 1), np.uint8)
     nr = C.c_int(0)
-    n = lib().ora_match_filter(_p(knn), nq, nt, _p(qk), _p(tk), ratio, _p(out), _p(mask),
-                               C.addressof(nr))
+    n = lib().ora_match_filter_x(_p(knn), _p(knn_rev) if knn_rev is not None else None, nq, nt, _p(qk),
+                                 _p(tk), ratio, _p(out), _p(mask), C.addressof(nr))
     return out[:n].copy(), mask[:nr.value].copy(), nr.value
 
 

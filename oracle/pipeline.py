@@ -11,7 +11,8 @@ class OracleStream:
     """One camera stream: keeps the previous features and track ages."""
 
     def __init__(self, camera=None, max_features=1000, fast_threshold=20, ratio=0.7,
-                 pnp_iters=100, pnp_threshold=8.0, pnp_confidence=0.99):
+                 pnp_iters=100, pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False):
+        self.cross_check = cross_check
         self.camera = camera  # (fx, fy, cx, cy) or None
         self.max_features = max_features
         self.fast_threshold = fast_threshold
@@ -53,7 +54,8 @@ class OracleStream:
             pk, pd = self.prev
             if len(pk) and len(kps):
                 knn = O.knn2(pd, desc)
-                m, _, nr = O.match_filter(knn, len(kps), pk, kps, self.ratio)
+                rev = O.knn2(desc, pd) if self.cross_check else None
+                m, _, nr = O.match_filter(knn, len(kps), pk, kps, self.ratio, knn_rev=rev)
                 out["matches"], out["n_ratio"] = m, nr
             tracked, ages = O.track_filter(out["matches"], self.prev_ages, len(kps))
             out["tracked"] = tracked

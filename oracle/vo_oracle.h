@@ -90,6 +90,18 @@ void ora_brief(const uint8_t *blur, int w, int h, int stride,
 int ora_detect(const uint8_t *gray, int w, int h, int stride, int max_features,
                int fast_threshold, ora_kp *kps, uint8_t *desc);
 
+/* ---- ImageProcessor (reference src/image_processor.cpp:41-79) ---------- */
+
+/* cv::equalizeHist */
+void ora_equalize_hist(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dstride);
+/* 8.8 fixed-point taps of cv::GaussianBlur on 8-bit data; n odd, 1..31; returns 0 on a bad n */
+int ora_gaussian_taps_q8(int n, double sigma, int *taps);
+/* cv::GaussianBlur(Size(n,n), sigma), whole image, BORDER_REFLECT_101 */
+int ora_gaussian_blur(const uint8_t *src, int w, int h, int stride, int n, double sigma, uint8_t *dst,
+                      int dstride);
+/* zero outside rows [h/4, 3h/4] */
+void ora_roi_mask(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dstride);
+
 /* ---- matching ------------------------------------------------------- */
 
 /* BFMatcher(NORM_HAMMING).knnMatch(query, train, k=2)
@@ -132,6 +144,10 @@ void ora_f_error(const float *p1, const float *p2, int n, const double *F,
 int ora_match_filter(const ora_knn2 *knn, int nq, int nt, const ora_kp *qk,
                      const ora_kp *tk, float ratio, ora_match *out,
                      uint8_t *ransac_mask, int *n_ratio);
+
+int ora_match_filter_x(const ora_knn2 *knn, const ora_knn2 *knn_rev, int nq, int nt,
+                       const ora_kp *qk, const ora_kp *tk, float ratio, ora_match *out,
+                       uint8_t *ransac_mask, int *n_ratio);
 
 /* backprojectAndFilter(use_curr=true) (reference src/frame_processor.cpp:230-308).
  * depth is float32 mm, row stride in elements.  Compacts matches in place,

@@ -383,3 +383,121 @@ int ora_track_filter(ora_match *m, int n, const int32_t *prev_age, int n_prev,
     }
     return n;
 }
+
+/* ------------------------------------------------------ ImageProcessor */
+
+/* [OCV-recall] cv::equalizeHist (imgproc/histogram.cpp): 256-bin histogram,
+ * first non-empty bin i0 maps to 0, scale = 255.f / (total - hist[i0]),
+ * lut[i] = saturate_cast<uchar>(cumsum * scale) (float product, round half
+ * to even); a constant image is filled with its value.
+ * reference src/image_processor.cpp:46 */
+void ora_equalize_hist(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dstride)
+{
+    int hist[256] = {0};
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) hist[src[(size_t)y * stride + x]]++;
+    const int total = w * h;
+    int i = 0;
+    while (!hist[i]) ++i;
+    uint8_t lut[256];
+    if (hist[i] == total) {
+        for (int k = 0; k < 256; k++) lut[k] = (uint8_t)i;
+    } else {
+        const float scale = (256 - 1.f) / (float)(total - hist[i]);
+        int sum = 0;
+        for (int k = 0; k <= i; k++) lut[k] = 0;
+        for (++i; i < 256; ++i) {
+            sum += hist[i];
+            long v = lrintf((float)sum * scale);
+            lut[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) dst[(size_t)y * dstride + x] = lut[src[(size_t)y * stride + x]];
+}
+
+/* [OCV-recall] 8.8 fixed-point Gaussian taps as cv::GaussianBlur builds them
+ * for 8-bit images (getGaussianKernelBitExact + error-diffused rounding in
+ * imgproc/smooth.dispatch.cpp): sigma <= 0 selects 0.3*((n-1)*0.5-1)+0.8 and,
+ * for n <= 7, the small fixed tables; the side taps are rounded to 1/256 with
+ * the rounding error carried to the next tap, the centre takes what is left
+ * of 256.  OpenCV evaluates exp() in softfloat; libm's exp can differ from it
+ * only in the last ulp, which moves a tap only at an exact .5 boundary. */
+int ora_gaussian_taps_q8(int n, double sigma, int *taps)
+{
+    static const double small_tab[4][7] = {
+        {1.0},
+        {0.25, 0.5, 0.25},
+        {0.0625, 0.25, 0.375, 0.25, 0.0625},
+        {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125}};
+    if (n < 1 || n > 31 || n % 2 == 0) return 0;
+    double k[31];
+    if (sigma <= 0 && n <= 7) {
+        for (int i = 0; i < n; i++) k[i] = small_tab[n >> 1][i];
+    } else {
+        const double sx = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+        const double scale2x = -0.5 / (sx * sx);
+        const int n2 = (n - 1) / 2;
+        double sum = 0;
+        for (int i = 0; i < n2; i++) {
+            const double x = i - n2;
+            k[i] = exp(scale2x * x * x);
+            sum += k[i];
+        }
+        sum *= 2;
+        sum += 1.0; /* centre tap, exp(0) */
+        const double inv = 1.0 / sum;
+        for (int i = 0; i < n2; i++) k[i] = k[n - 1 - i] = k[i] * inv;
+        k[n2] = inv;
+    }
+    const int n2 = n / 2;
+    double err = 0;
+    int sum = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = k[i] * 256.0 + err;
+        const int v = (int)lrint(adj);
+        err = adj - (double)v;
+        taps[i] = taps[n - 1 - i] = v;
+        sum += v;
+    }
+    taps[n2] = 256 - 2 * sum;
+    return 1;
+}
+
+/* cv::GaussianBlur(src, dst, Size(n,n), sigma) on a whole 8-bit image: the
+ * fixed-point path -- rows in 8.8, columns in 16.16, (sum + 2^15) >> 16,
+ * BORDER_REFLECT_101.  reference src/image_processor.cpp:57-59 */
+int ora_gaussian_blur(const uint8_t *src, int w, int h, int stride, int n, double sigma, uint8_t *dst,
+                      int dstride)
+{
+    int taps[31];
+    if (!ora_gaussian_taps_q8(n, sigma, taps)) return 0;
+    const int r = n / 2;
+    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int i = -r; i <= r; i++) s += (uint32_t)taps[i + r] * src[(size_t)y * stride + reflect101(x + i, w)];
+            tmp[(size_t)y * w + x] = (uint16_t)(s > 65535u ? 65535u : s);
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint32_t s = 0;
+            for (int i = -r; i <= r; i++) s += (uint32_t)taps[i + r] * tmp[(size_t)reflect101(y + i, h) * w + x];
+            s = (s + 32768u) >> 16;
+            dst[(size_t)y * dstride + x] = (uint8_t)(s > 255u ? 255u : s);
+        }
+    free(tmp);
+    return 1;
+}
+
+/* the centre-band mask of ImageProcessor::createMask: a filled cv::rectangle
+ * from (0, h/4) to (w, 3h/4), corners inclusive, ANDed with the image.
+ * reference src/image_processor.cpp:65-79 */
+void ora_roi_mask(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dstride)
+{
+    const int y0 = h / 4, y1 = h * 3 / 4;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[(size_t)y * dstride + x] = (y >= y0 && y <= y1) ? src[(size_t)y * stride + x] : 0;
+}

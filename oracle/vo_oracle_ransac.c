@@ -343,8 +343,23 @@ int ora_match_filter(const ora_knn2 *knn, int nq, int nt, const ora_kp *qk,
                      const ora_kp *tk, float ratio, ora_match *out,
                      uint8_t *ransac_mask, int *n_ratio)
 {
+    return ora_match_filter_x(knn, 0, nq, nt, qk, tk, ratio, out, ransac_mask, n_ratio);
+}
+
+/* the same with an optional mutual-nearest cross-check between the ratio
+ * test and RANSAC (knn_rev = kNN of the swapped pair, or NULL) */
+int ora_match_filter_x(const ora_knn2 *knn, const ora_knn2 *knn_rev, int nq, int nt,
+                       const ora_kp *qk, const ora_kp *tk, float ratio, ora_match *out,
+                       uint8_t *ransac_mask, int *n_ratio)
+{
     ora_match *good = (ora_match *)malloc(sizeof(ora_match) * (size_t)(nq > 0 ? nq : 1));
     int ng = ora_ratio_test(knn, nq, nt, ratio, qk, tk, good);
+    if (knn_rev) {
+        int k = 0;
+        for (int i = 0; i < ng; i++)
+            if (knn_rev[good[i].train].idx0 == good[i].query) good[k++] = good[i];
+        ng = k;
+    }
     if (n_ratio) *n_ratio = ng;
     int nout = 0;
     if (ng >= 8) {

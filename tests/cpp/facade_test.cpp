@@ -11,6 +11,15 @@
 #include <vector>
 
 #include "visual_odometry/frame_processor.hpp"
+#include "visual_odometry/image_processor.hpp"
+
+static unsigned long long fnv1a(const cv::Mat &m)
+{
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int y = 0; y < m.rows; y++)
+        for (int x = 0; x < m.cols; x++) hsh = (hsh ^ m.ptr<uint8_t>(y)[x]) * 1099511628211ull;
+    return hsh;
+}
 
 int main(int argc, char **argv)
 {
@@ -77,6 +86,27 @@ int main(int argc, char **argv)
                 for (int x = 0; x < w; x++)
                     for (int k = 0; k < 3; k++) bgr.ptr<uint8_t>(y)[3 * x + k] = rgb.ptr<uint8_t>(y)[c * x + k];
             prev_feat = detector->detectFeatures(bgr);
+
+            // ImageProcessor as declared in vo_node.hpp:56 (defaults, then histogram equalisation + 5x5)
+            vo::ImageProcessor ip;
+            vo::ProcessedImages p0 = ip.processImage(bgr);
+            std::printf("improc plain %llx enhanced_empty %d\n", fnv1a(p0.gray), (int)p0.enhanced.empty());
+            vo::ProcessedImages p1 = ip.processImage(bgr, true);
+            std::printf("improc default %llx %llx %llx %llx\n", fnv1a(p1.gray), fnv1a(p1.enhanced), fnv1a(p1.denoised),
+                        fnv1a(p1.masked));
+            ip.setEnableHistogramEq(true);
+            ip.setGaussianBlurSize(5);
+            ip.setGaussianSigma(1.4);
+            vo::ProcessedImages p2 = ip.processImage(bgr, true);
+            std::printf("improc histeq5 %llx %llx %llx %llx\n", fnv1a(p2.gray), fnv1a(p2.enhanced), fnv1a(p2.denoised),
+                        fnv1a(p2.masked));
+            ip.setGaussianBlurSize(4);
+            try {
+                ip.processImage(bgr, true);
+                std::printf("improc_even no_throw\n");
+            } catch (const std::exception &) {
+                std::printf("improc_even threw\n");
+            }
         }
     }
     // error convention: detectFeatures swallows, processFrame throws

@@ -297,3 +297,31 @@ def test_golden_hashes(oracle):
     got = _golden_cases(oracle)
     exp = json.load(open(GOLDEN))
     assert got == exp
+
+
+def test_gaussian_taps_and_equalize_hist(oracle):
+    # taps always sum to 256 and are symmetric; known small cases
+    assert list(oracle.gaussian_taps_q8(3, 0.0)) == [64, 128, 64]
+    assert list(oracle.gaussian_taps_q8(5, 0.0)) == [16, 64, 96, 64, 16]
+    assert list(oracle.gaussian_taps_q8(3, 1.0)) == [70, 116, 70]
+    for n, s in ((7, 2.0), (9, 0.0), (31, 6.0), (15, 1.1)):
+        t = oracle.gaussian_taps_q8(n, s)
+        assert t.sum() == 256 and np.array_equal(t, t[::-1])
+    with pytest.raises(ValueError):
+        oracle.gaussian_taps_q8(4, 1.0)
+    # a constant image passes through the blur unchanged; an impulse spreads as the outer product of the taps
+    g = np.full((20, 30), 200, np.uint8)
+    assert (oracle.gaussian_blur(g, 5, 1.0) == 200).all()
+    imp = np.zeros((21, 21), np.uint8); imp[10, 10] = 255
+    t = oracle.gaussian_taps_q8(5, 1.0).astype(np.int64)
+    exp = (np.outer(t, t) * 255 + 32768) >> 16
+    assert np.array_equal(oracle.gaussian_blur(imp, 5, 1.0)[8:13, 8:13], exp)
+    # equalizeHist against a direct numpy statement of the LUT
+    rng = np.random.default_rng(3)
+    img = rng.integers(30, 200, (50, 70), dtype=np.uint8)
+    hist = np.bincount(img.ravel(), minlength=256)
+    i0 = np.flatnonzero(hist)[0]
+    scale = np.float32(255.0) / np.float32(img.size - hist[i0])
+    cum = np.cumsum(np.where(np.arange(256) > i0, hist, 0)).astype(np.float32)
+    lut = np.clip(np.rint(cum * scale), 0, 255).astype(np.uint8)
+    assert np.array_equal(oracle.equalize_hist(img), lut[img])

@@ -85,6 +85,20 @@ def test_frame_processor_facade_matches_oracle(oracle, imu_tx):
     m, _, _ = oracle.match_filter(oracle.knn2(d0, d1), len(k1), k0, k1, 0.7)
     assert int(ops[2]) == len(k1) and int(ops[4]) == len(k1) and int(ops[6]) == len(m)
 
+    # ImageProcessor facade on the same BGR frame
+    def fnv(a):
+        hsh = 1469598103934665603
+        for b in a.tobytes():
+            hsh = ((hsh ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%x" % hsh
+    bgr0 = np.ascontiguousarray(seq["frames"][0][..., :3])
+    ip = {ln.split()[1]: ln.split()[2:] for ln in lines if ln.startswith("improc ")}
+    assert ip["plain"] == [fnv(g0), "enhanced_empty", "1"]
+    for key, kw in (("default", {}), ("histeq5", dict(hist_eq=True, blur_size=5, sigma=1.4))):
+        r = oracle.process_image(bgr0, enhance=True, **kw)
+        assert ip[key] == [fnv(r[k]) for k in ("gray", "enhanced", "denoised", "masked")]
+    assert "improc_even threw" in lines
+
     # error conventions: detectFeatures swallows and returns empty, processFrame throws
     assert "empty_detect kp 0" in lines
     assert "gray_process threw" in lines

@@ -116,3 +116,18 @@ def test_batch_reset_makes_first_frame(ctx, oracle):
     ctx.batch_reset()
     ctx.batch_submit(seq["frames"][1:2]); r2 = ctx.batch_wait()
     assert r2["n_matches"][0] == 0 and r2["n_keypoints"][0] == r1["n_keypoints"][0]
+
+
+def test_batch_pipeline_cross_check(ctx, oracle):
+    """Mutual-nearest filtering between the ratio test and RANSAC, whole pipeline."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    seq = synth.make_sequence(cam, 4, seed=4242, channels=3)
+    ref = OracleStream(K, 1000, 20, cross_check=True)
+    ctx.batch_configure(cam.width, cam.height, 3, n_streams=1, frames_per_stream=4, max_features=1000,
+                        camera=K, cross_check=True)
+    ctx.batch_submit(seq["frames"], seq["depth"])
+    res = ctx.batch_wait()
+    for f in range(4):
+        _compare_frame(ctx, res, f, ref.process(seq["frames"][f], seq["depth"][f]), pose=True)

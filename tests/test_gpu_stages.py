@@ -141,3 +141,44 @@ def test_match_features_end_to_end(ctx, oracle, vga_seq):
     m = ctx.match(k0, d0, k1, d1, 0.7)
     assert len(m) == len(m_ref) > 50
     assert np.array_equal(m, m_ref)
+
+
+def test_match_features_cross_check(ctx, oracle, vga_seq):
+    k0, d0, k1, d1, _ = _pair_points(oracle, vga_seq)
+    fwd, rev = oracle.knn2(d0, d1), oracle.knn2(d1, d0)
+    m_ref, _, n_ratio = oracle.match_filter(fwd, len(k1), k0, k1, 0.7, knn_rev=rev)
+    m_plain, _, n_plain = oracle.match_filter(fwd, len(k1), k0, k1, 0.7)
+    m = ctx.match(k0, d0, k1, d1, 0.7, cross_check=True)
+    assert np.array_equal(m, m_ref) and 50 < len(m)
+    assert n_ratio <= n_plain
+    # every kept match is a mutual nearest neighbour
+    assert all(rev["idx0"][t] == q for q, t in zip(m["query"], m["train"]))
+
+
+@pytest.mark.parametrize("shape,cn", [((480, 640), 3), ((375, 1241), 1), ((61, 67), 3), ((720, 1280), 3)])
+@pytest.mark.parametrize("hist_eq,blur_size,sigma", [(False, 3, 1.0), (True, 3, 1.0), (True, 7, 0.0),
+                                                      (False, 1, 1.0), (True, 31, 6.0), (False, 9, -1.0)])
+def test_image_process(ctx, oracle, shape, cn, hist_eq, blur_size, sigma):
+    """ImageProcessor::processImage, every plane bit-exact."""
+    rng = np.random.default_rng(shape[0] * 7 + blur_size)
+    h, w = shape
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img = (img.astype(np.int32) * 3 // 4 + 20).astype(np.uint8)  # leave empty bins at both ends
+    if cn == 3:
+        img = np.stack([img, np.roll(img, 1, 1), np.roll(img, 1, 0)], -1)
+    ref = oracle.process_image(img, True, blur_size, sigma, hist_eq)
+    got = ctx.process_image(img, True, blur_size, sigma, hist_eq)
+    for k in ("gray", "enhanced", "denoised", "masked"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert ref["masked"][: h // 4].max() == 0 and ref["masked"][h * 3 // 4 + 1:].max() == 0
+    assert np.array_equal(ref["masked"][h // 4: h * 3 // 4 + 1], ref["denoised"][h // 4: h * 3 // 4 + 1])
+    plain = ctx.process_image(img, False)
+    assert list(plain) == ["gray"] and np.array_equal(plain["gray"], ref["gray"])
+
+
+def test_image_process_rejects_even_kernel(ctx):
+    img = np.zeros((64, 64), np.uint8)
+    with pytest.raises(Exception):
+        ctx.process_image(img, True, 4, 1.0)
+    flat = ctx.process_image(np.full((64, 64), 37, np.uint8), True, 3, 1.0, True)
+    assert (flat["enhanced"] == 37).all()  # cv::equalizeHist leaves a constant image alone

@@ -39,7 +39,7 @@ class VoBatchCfg(C.Structure):
                 ("f_threshold", C.c_double), ("f_confidence", C.c_double), ("f_max_iters", C.c_int),
                 ("enable_pose", C.c_int), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
                 ("cy", C.c_double), ("pnp_iters", C.c_int), ("pnp_threshold", C.c_double),
-                ("pnp_confidence", C.c_double)]
+                ("pnp_confidence", C.c_double), ("cross_check", C.c_int)]
 
 
 RESULT_DTYPE = np.dtype([("n_keypoints", "<i4"), ("n_ratio", "<i4"), ("f_found", "<i4"),
@@ -70,6 +70,9 @@ EXPORTS = {
     "vo_find_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                              _P, _P, _P, _P]),
     "vo_match_features": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P]),
+    "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, _P, _P, _P, _P, C.c_int]),
+    "vo_match_features_ex": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P]),
     "vo_solve_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_int, C.c_double, C.c_double, _P, _P, _P, _P, _P]),
     "vo_batch_configure": (C.c_int, [_P, C.POINTER(VoBatchCfg)]),
@@ -193,16 +196,26 @@ class Context:
             C.addressof(found), C.addressof(iters)))
         return bool(found.value), F.reshape(3, 3), mask[:n].copy(), iters.value
 
-    def match(self, prev_kps, prev_desc, curr_kps, curr_desc, ratio=0.7) -> np.ndarray:
+    def process_image(self, img: np.ndarray, enhance=False, blur_size=3, sigma=1.0, hist_eq=False) -> dict:
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        cn = 1 if img.ndim == 2 else img.shape[2]
+        planes = [np.empty((h, w), np.uint8) for _ in range(4 if enhance else 1)]
+        ptrs = [_ptr(p) for p in planes] + [None] * (4 - len(planes))
+        self._check(self._lib.vo_image_process(self._h, _ptr(img), w, h, w * cn, cn, int(enhance), int(hist_eq),
+                                               blur_size, sigma, *ptrs, w))
+        return dict(zip(("gray", "enhanced", "denoised", "masked"), planes))
+
+    def match(self, prev_kps, prev_desc, curr_kps, curr_desc, ratio=0.7, cross_check=False) -> np.ndarray:
         prev_kps = np.ascontiguousarray(prev_kps, KP_DTYPE)
         curr_kps = np.ascontiguousarray(curr_kps, KP_DTYPE)
         prev_desc = np.ascontiguousarray(prev_desc, np.uint8)
         curr_desc = np.ascontiguousarray(curr_desc, np.uint8)
         out = np.zeros(max(len(prev_kps), 1), MATCH_DTYPE)
         n = C.c_int(0)
-        self._check(self._lib.vo_match_features(self._h, _ptr(prev_kps), _ptr(prev_desc), len(prev_kps),
-                                                _ptr(curr_kps), _ptr(curr_desc), len(curr_kps), ratio,
-                                                _ptr(out), C.addressof(n)))
+        self._check(self._lib.vo_match_features_ex(self._h, _ptr(prev_kps), _ptr(prev_desc), len(prev_kps),
+                                                   _ptr(curr_kps), _ptr(curr_desc), len(curr_kps), ratio,
+                                                   int(cross_check), _ptr(out), C.addressof(n)))
         return out[:n.value].copy()
 
     def solve_pnp_ransac(self, obj, img, fx, fy, cx, cy, iters=100, thr=8.0, conf=0.99):
@@ -223,13 +236,13 @@ class Context:
     def batch_configure(self, width, height, channels, n_streams=1, frames_per_stream=1,
                         max_features=1000, fast_threshold=20, ratio=0.7, f_threshold=3.0,
                         f_confidence=0.99, f_max_iters=1000, camera=None, pnp_iters=100,
-                        pnp_threshold=8.0, pnp_confidence=0.99):
+                        pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False):
         """camera: (fx, fy, cx, cy) enables depth back-projection + PnP."""
         fx, fy, cx, cy = camera if camera is not None else (0.0, 0.0, 0.0, 0.0)
         cfg = VoBatchCfg(width, height, channels, n_streams, frames_per_stream, max_features,
                          fast_threshold, ratio, f_threshold, f_confidence, f_max_iters,
                          1 if camera is not None else 0, fx, fy, cx, cy, pnp_iters, pnp_threshold,
-                         pnp_confidence)
+                         pnp_confidence, int(cross_check))
         self._check(self._lib.vo_batch_configure(self._h, C.byref(cfg)))
         self._bcfg = cfg
         self._batch = n_streams * frames_per_stream

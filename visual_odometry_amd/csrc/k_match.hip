@@ -93,12 +93,16 @@ constexpr int FIN_THREADS = 1024;
 // One block per frame pair: merge the split partial top-2 lists, emit the
 // vo_knn2 record of every query, run the ratio test
 // (reference src/feature_matcher.cpp:34-49: float32 d0 < ratio * d1) and
-// append survivors in query order.
+// append survivors in query order.  With partial_rev (kNN of the swapped
+// pair) a survivor must in addition be the mutual nearest neighbour
+// (cross-check, an extension: the reference builds its BFMatcher with
+// crossCheck = false, src/feature_matcher.cpp:8).
 __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__restrict__ partial,
                                                                 const vo_kp *__restrict__ kps, int kp_stride,
                                                                 const int *__restrict__ nkp,
                                                                 const int *__restrict__ q_slot,
                                                                 const int *__restrict__ t_slot, float ratio,
+                                                                const uint2 *__restrict__ partial_rev,
                                                                 vo_knn2 *__restrict__ knn,
                                                                 vo_match *__restrict__ good,
                                                                 int *__restrict__ n_good)
@@ -137,6 +141,14 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
             if (k1 != 0xffffffffu) { r.idx1 = (int)(k1 & 0xffffu); r.dist1 = (int)(k1 >> 16); }
             if (knn) knn[(size_t)pair * kp_stride + q] = r;
             keep = r.idx1 >= 0 && (float)r.dist0 < ratio * (float)r.dist1;
+            if (keep && partial_rev) {
+                // cross-check: q must also be the nearest query of its best train descriptor
+                uint32_t b0 = 0xffffffffu;
+#pragma unroll
+                for (int s = 0; s < kKnnSplits; s++)
+                    b0 = min(b0, partial_rev[((size_t)pair * kKnnSplits + s) * kp_stride + r.idx0].x);
+                keep = (int)(b0 & 0xffffu) == q;
+            }
         } else if (q < nq && knn) {
             knn[(size_t)pair * kp_stride + q] = r;
         }
@@ -166,11 +178,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
 }
 
 void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride, const int *nkp,
-                           const int *q_slot, const int *t_slot, float ratio, vo_knn2 *knn, vo_match *good,
-                           int *n_good, int pairs, hipStream_t s)
+                           const int *q_slot, const int *t_slot, float ratio, const uint2 *partial_rev,
+                           vo_knn2 *knn, vo_match *good, int *n_good, int pairs, hipStream_t s)
 {
     hipLaunchKernelGGL(k_match_finalize, dim3(pairs), dim3(FIN_THREADS), 0, s, partial, kps, kp_stride, nkp,
-                       q_slot, t_slot, ratio, knn, good, n_good);
+                       q_slot, t_slot, ratio, partial_rev, knn, good, n_good);
 }
 
 }  // namespace vo

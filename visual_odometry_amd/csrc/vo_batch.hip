@@ -180,7 +180,7 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
 
     c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
                       b.fast_threshold, B, /*first_slot=*/S);
-    c->enqueue_match(B, b.ratio, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
+    c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
     c->mark(6);
     launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
                       c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "../../include/vo_orb_pattern.h"
@@ -134,6 +135,7 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMalloc(&d_nkp, sizeof(int) * slots));
     HIP_TRY(ctx, hipMalloc(&d_pattern, 1024));
     HIP_TRY(ctx, hipMalloc(&d_partial, sizeof(uint2) * (size_t)kKnnSplits * kp_stride * B));
+    HIP_TRY(ctx, hipMalloc(&d_partial_rev, sizeof(uint2) * (size_t)kKnnSplits * kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_knn, sizeof(vo_knn2) * (size_t)kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_good, sizeof(vo_match) * (size_t)kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_ngood, sizeof(int) * B));
@@ -168,6 +170,8 @@ int vo_ctx::allocate()
     std::vector<uint32_t> rng(1 << 16);
     fill_rng_table(rng);
     rng_len = (int)rng.size();
+    HIP_TRY(ctx, hipMalloc(&d_aux, plane_bytes));
+    HIP_TRY(ctx, hipMalloc(&d_hist, 256 * sizeof(uint32_t) + 256));
     HIP_TRY(ctx, hipMalloc(&d_rng, sizeof(uint32_t) * rng.size()));
     HIP_TRY(ctx, hipMemcpy(d_rng, rng.data(), sizeof(uint32_t) * rng.size(), hipMemcpyHostToDevice));
 
@@ -181,7 +185,7 @@ int vo_ctx::allocate()
 void vo_ctx::release()
 {
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_count, d_kps, d_desc, d_nkp, d_pattern,
-                    d_partial, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng,
+                    d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results};
     for (void *p : ptrs)
@@ -259,6 +263,86 @@ int vo_blur7(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, uint8_t *
     return finish(c, "vo_blur7");
 }
 
+// cv::GaussianBlur's 8.8 fixed-point taps for 8-bit images: normalised
+// Gaussian (small fixed tables for sigma <= 0 and n <= 7), side taps rounded
+// to 1/256 with the rounding error carried forward, centre = 256 - the rest.
+static bool gaussian_taps_q8(int n, double sigma, uint16_t *taps)
+{
+    if (n < 1 || n > 31 || (n & 1) == 0) return false;
+    const int half = n / 2;
+    std::vector<double> g(n);
+    if (sigma <= 0 && n <= 7) {
+        static const double tab[4][4] = {{1.0}, {0.25, 0.5}, {0.0625, 0.25, 0.375}, {0.03125, 0.109375, 0.21875, 0.28125}};
+        for (int i = 0; i <= half; i++) g[i] = g[n - 1 - i] = tab[half][i];
+    } else {
+        const double sd = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+        const double a = -0.5 / (sd * sd);
+        double side = 0;
+        for (int i = 0; i < half; i++) {
+            const double x = i - half;
+            g[i] = std::exp(a * x * x);
+            side += g[i];
+        }
+        const double inv = 1.0 / (side * 2 + 1.0);
+        for (int i = 0; i < half; i++) g[i] = g[n - 1 - i] = g[i] * inv;
+        g[half] = inv;
+    }
+    double carry = 0;
+    int used = 0;
+    for (int i = 0; i < half; i++) {
+        const double want = g[i] * 256.0 + carry;
+        const int q = (int)std::lrint(want);
+        carry = want - (double)q;
+        taps[i] = taps[n - 1 - i] = (uint16_t)q;
+        used += 2 * q;
+    }
+    taps[half] = (uint16_t)(256 - used);
+    return true;
+}
+
+int vo_image_process(vo_ctx *c, const uint8_t *src, int w, int h, int src_stride, int channels, int enhance,
+                     int hist_eq, int blur_size, double sigma, uint8_t *gray, uint8_t *enhanced,
+                     uint8_t *denoised, uint8_t *masked, int out_stride)
+{
+    int rc = check_frame(c, w, h, "vo_image_process");
+    if (rc) return rc;
+    if (!src || !gray || src_stride < w * channels || out_stride < w)
+        return fail(c, VO_ERR_ARG, "vo_image_process: bad arguments");
+    if (channels != 1 && channels != 3)
+        return fail(c, VO_ERR_UNSUPPORTED, "vo_image_process: %d-channel input (1 or 3 expected)", channels);
+    if (enhance && (!enhanced || !denoised || !masked))
+        return fail(c, VO_ERR_ARG, "vo_image_process: enhance needs all four output planes");
+    uint16_t taps[31] = {256};
+    int n_taps = 1;
+    if (enhance && blur_size > 1) {
+        if (!gaussian_taps_q8(blur_size, sigma, taps))
+            return fail(c, VO_ERR_ARG, "vo_image_process: blur size %d is not odd and <= 31", blur_size);
+        n_taps = blur_size;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (channels == 3) {
+        if ((rc = stage_image(c, src, w * 3, h, src_stride))) return rc;
+        launch_gray(c->d_in, w, h, w * 3, 0, 3, c->plane(c->d_gray), 1, c->gc, c->stream);
+    } else {
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_gray, c->pitch, src, src_stride, w, h, hipMemcpyDefault, c->stream));
+    }
+    HIP_TRY(c, hipMemcpy2DAsync(gray, out_stride, c->d_gray, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    if (enhance) {
+        uint8_t *lut = nullptr;
+        if (hist_eq) {
+            lut = reinterpret_cast<uint8_t *>(c->d_hist + 256);
+            launch_hist256(c->d_gray, w, h, c->pitch, c->d_hist, c->stream);
+            launch_equalize_lut(c->d_hist, w * h, lut, c->stream);
+        }
+        launch_enhance_blur_mask(c->d_gray, w, h, c->pitch, lut, n_taps, taps, c->d_score, c->d_blur, c->d_aux,
+                                 c->stream);
+        HIP_TRY(c, hipMemcpy2DAsync(enhanced, out_stride, c->d_score, c->pitch, w, h, hipMemcpyDefault, c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(denoised, out_stride, c->d_blur, c->pitch, w, h, hipMemcpyDefault, c->stream));
+        HIP_TRY(c, hipMemcpy2DAsync(masked, out_stride, c->d_aux, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    }
+    return finish(c, "vo_image_process");
+}
+
 int vo_detect(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int max_features, int fast_threshold,
               vo_kp *kps, uint8_t *desc, int *n_out)
 {
@@ -315,7 +399,7 @@ int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *trai
     if ((rc = set_single_pair(c))) return rc;
     launch_knn2(c->d_desc, (size_t)c->kp_stride * 32, c->d_nkp, c->d_qslot, c->d_tslot, c->kp_stride,
                 c->d_partial, c->kp_stride, 1, c->stream);
-    launch_match_finalize(c->d_partial, c->d_kps, c->kp_stride, c->d_nkp, c->d_qslot, c->d_tslot, 0.7f,
+    launch_match_finalize(c->d_partial, c->d_kps, c->kp_stride, c->d_nkp, c->d_qslot, c->d_tslot, 0.7f, nullptr,
                           c->d_knn, c->d_good, c->d_ngood, 1, c->stream);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_knn, sizeof(vo_knn2) * nq, hipMemcpyDefault, c->stream));
     return finish(c, "vo_knn2_hamming");
@@ -361,7 +445,14 @@ int vo_find_fundamental_ransac(vo_ctx *c, const float *p1, const float *p2, int 
 }
 
 int vo_match_features(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_desc, int n_prev, const vo_kp *curr_kps,
-             const uint8_t *curr_desc, int n_curr, float ratio, vo_match *out, int *n_out)
+                      const uint8_t *curr_desc, int n_curr, float ratio, vo_match *out, int *n_out)
+{
+    return vo_match_features_ex(c, prev_kps, prev_desc, n_prev, curr_kps, curr_desc, n_curr, ratio, 0, out, n_out);
+}
+
+int vo_match_features_ex(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_desc, int n_prev,
+                         const vo_kp *curr_kps, const uint8_t *curr_desc, int n_curr, float ratio, int cross_check,
+                         vo_match *out, int *n_out)
 {
     if (!c) return VO_ERR_ARG;
     if (!n_out || n_prev < 0 || n_curr < 0 || n_prev > c->cfg.max_features || n_curr > c->cfg.max_features)
@@ -376,7 +467,7 @@ int vo_match_features(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_desc
     if ((rc = upload_features(c, c->op_slot0, prev_kps, prev_desc, n_prev))) return rc;
     if ((rc = upload_features(c, c->op_slot1, curr_kps, curr_desc, n_curr))) return rc;
     if ((rc = set_single_pair(c))) return rc;
-    c->enqueue_match(1, ratio, FRansacParams{3.0, 0.99, 1000});
+    c->enqueue_match(1, ratio, cross_check != 0, FRansacParams{3.0, 0.99, 1000});
     if ((rc = finish(c, "vo_match_features"))) return rc;
     int info[4];
     HIP_TRY(c, hipMemcpy(info, c->d_info, sizeof(info), hipMemcpyDeviceToHost));
@@ -405,14 +496,17 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
                  d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
 }
 
-void vo_ctx::enqueue_match(int pairs, float ratio, FRansacParams prm)
+void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacParams prm)
 {
     mark(3);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
                 pairs, stream);
+    if (cross_check)  // the same pairs with the roles of query and train swapped
+        launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_tslot, d_qslot, kp_stride, d_partial_rev, kp_stride,
+                    pairs, stream);
     mark(4);
-    launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio, d_knn, d_good,
-                          d_ngood, pairs, stream);
+    launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio,
+                          cross_check ? d_partial_rev : nullptr, d_knn, d_good, d_ngood, pairs, stream);
     mark(5);
     launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
                     stream);

@@ -22,12 +22,14 @@ struct vo_ctx {
 
     uint8_t *d_in = nullptr;     // staging for frames handed over from the host
     uint8_t *d_gray = nullptr, *d_score = nullptr, *d_blur = nullptr;
+    uint8_t *d_aux = nullptr;    // fourth plane of the image-processing operator (masked output)
+    uint32_t *d_hist = nullptr;  // 256 bins + 256-byte equalisation table behind them
     uint32_t *d_cand = nullptr, *d_cand_count = nullptr;
     vo_kp *d_kps = nullptr;
     uint8_t *d_desc = nullptr;
     int *d_nkp = nullptr;
     int8_t *d_pattern = nullptr;
-    uint2 *d_partial = nullptr;
+    uint2 *d_partial = nullptr, *d_partial_rev = nullptr;
     vo_knn2 *d_knn = nullptr;
     vo_match *d_good = nullptr;
     int *d_ngood = nullptr;
@@ -79,5 +81,5 @@ struct vo_ctx {
     void enqueue_detect(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
                         int channels, int max_features, int fast_threshold, int batch, int first_slot);
     // kNN-2 + ratio + F-RANSAC + motion filter for `pairs` (d_qslot/d_tslot) pairs
-    void enqueue_match(int pairs, float ratio, vo::FRansacParams prm);
+    void enqueue_match(int pairs, float ratio, bool cross_check, vo::FRansacParams prm);
 };

@@ -66,12 +66,22 @@ void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp,
                  const int *q_slot, const int *t_slot, int kp_stride,
                  uint2 *partial, int max_n, int pairs, hipStream_t s);
 
-// Merge the split partials into vo_knn2 records, apply the ratio test and
-// write the surviving matches in query order.
+// ImageProcessor stages (reference src/image_processor.cpp:41-79), one plane.
+void launch_hist256(const uint8_t *img, int w, int h, int pitch, uint32_t *hist, hipStream_t s);
+void launch_equalize_lut(const uint32_t *hist, int total, uint8_t *lut, hipStream_t s);
+// src -> [lut] -> enh; separable 8.8 fixed-point Gaussian (n_taps odd, <= 31,
+// taps sum to 256) -> den; den with rows outside [h/4, 3h/4] zeroed -> msk.
+// Null outputs are skipped.  Planes must be padded to whole 128x16 tiles.
+void launch_enhance_blur_mask(const uint8_t *src, int w, int h, int pitch, const uint8_t *lut, int n_taps,
+                              const uint16_t *taps, uint8_t *enh, uint8_t *den, uint8_t *msk, hipStream_t s);
+
+// Merge the split partials into vo_knn2 records, apply the ratio test (and,
+// when partial_rev holds the kNN of the swapped pair, the mutual-nearest
+// cross-check) and write the surviving matches in query order.
 void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride,
                            const int *nkp, const int *q_slot, const int *t_slot,
-                           float ratio, vo_knn2 *knn, vo_match *good,
-                           int *n_good, int pairs, hipStream_t s);
+                           float ratio, const uint2 *partial_rev, vo_knn2 *knn,
+                           vo_match *good, int *n_good, int pairs, hipStream_t s);
 
 struct FRansacParams {
     double threshold, confidence;
