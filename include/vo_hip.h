@@ -139,6 +139,31 @@ int vo_match_features(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev_de
                       int n_prev, const vo_kp *curr_kps, const uint8_t *curr_desc,
                       int n_curr, float ratio, vo_match *out, int *n_out);
 
+/* The full ORB detector: what the cv::ORB object the reference creates
+ * (cv::ORB::create(max_features, scale_factor, n_levels), reference
+ * src/feature_detector.cpp:18-22, setters :97-123) computes in
+ * detectAndCompute(): an n-level INTER_LINEAR_EXACT pyramid, per level FAST
+ * (threshold, NMS) -> 31 px border -> best 2*quota by FAST score -> Harris
+ * response -> best quota (boundary ties kept), intensity-centroid angle,
+ * pt scaled to level-0 coordinates, rBRIEF steered by the angle on the 7x7
+ * Gaussian of the level.  The reference itself never calls this path (it
+ * feeds cv::FAST corners to ORB::compute, :59-73 = vo_detect); it is what the
+ * setMaxFeatures / setScaleFactor / setNLevels interface describes.
+ * Keypoints come out level by level, raster order inside a level (OpenCV's
+ * order inside a level is unspecified).  At most min(cap, the context's
+ * feature capacity) keypoints are returned.  1 < scale_factor <= 2,
+ * 1 <= nlevels <= 8. */
+int vo_detect_orb(vo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
+                  int nfeatures, float scale_factor, int nlevels, int fast_threshold,
+                  vo_kp *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Diagnostic: copy pyramid level `level` of frame `frame` of the last ORB
+ * detection (operator or batch) to host memory; blurred != 0 selects the
+ * 7x7-Gaussian version the descriptors were sampled from.  dst may be null to
+ * query the level size only. */
+int vo_orb_get_level(vo_ctx *ctx, int frame, int level, int blurred, uint8_t *dst,
+                     int dst_stride, int *w_out, int *h_out);
+
 /* ImageProcessor::processImage (reference src/image_processor.cpp:6-79,
  * include/visual_odometry/image_processor.hpp:8-38).  gray = BGR2GRAY of a
  * 3-channel frame or a copy of a 1-channel one.  With enhance != 0 also:
@@ -202,6 +227,9 @@ typedef struct {
     int pnp_iters;                    /* reference 100 */
     double pnp_threshold, pnp_confidence; /* reference 8.0, 0.99 */
     int cross_check;                  /* mutual-nearest filter after the ratio test (reference: 0) */
+    int orb_levels;                   /* 0: FAST + ORB::compute as the reference runs it; 1..8: the full
+                                         ORB detector (vo_detect_orb) with that many pyramid levels */
+    float orb_scale_factor;           /* pyramid scale factor of the full detector (<= 0: 1.2) */
 } vo_batch_cfg;
 
 typedef struct {

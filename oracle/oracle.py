@@ -55,6 +55,17 @@ def lib():
                                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.ora_match_filter_x.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_fast_atan2.restype = C.c_float
+        _lib.ora_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.ora_harris_response.restype = C.c_float
+        _lib.ora_harris_response.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.ora_ic_angle.restype = C.c_float
+        _lib.ora_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.ora_orb_level_sizes.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
+        _lib.ora_orb_quotas.argtypes = [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        _lib.ora_orb_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -156,6 +167,71 @@ def detect(g: np.ndarray, max_features: int = 1000, fast_threshold: int = 20):
     desc = np.zeros((max(max_features, 1), 32), np.uint8)
     n = lib().ora_detect(_p(g), w, h, w, max_features, fast_threshold, _p(kps), _p(desc))
     return kps[:n].copy(), desc[:n].copy()
+
+
+def orb_levels(w, h, scale_factor=1.2, nlevels=8):
+    lw, lh = np.zeros(nlevels, np.int32), np.zeros(nlevels, np.int32)
+    ls = np.zeros(nlevels, np.float32)
+    lib().ora_orb_level_sizes(w, h, scale_factor, nlevels, _p(lw), _p(lh), _p(ls))
+    return lw, lh, ls
+
+
+def orb_quotas(nfeatures, scale_factor=1.2, nlevels=8):
+    q = np.zeros(nlevels, np.int32)
+    lib().ora_orb_quotas(nfeatures, scale_factor, nlevels, _p(q))
+    return q
+
+
+def resize_linear_exact(g: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().ora_resize_linear_exact(_p(g), w, h, w, _p(out), dw, dh, dw)
+    return out
+
+
+def fast_atan2(y, x):
+    return float(lib().ora_fast_atan2(y, x))
+
+
+def harris_response(g, x, y):
+    g = np.ascontiguousarray(g)
+    return float(lib().ora_harris_response(_p(g), g.shape[1], x, y))
+
+
+def ic_angle(g, x, y):
+    g = np.ascontiguousarray(g)
+    return float(lib().ora_ic_angle(_p(g), g.shape[1], x, y))
+
+
+def orb_umax():
+    u = np.zeros(32, np.int32)
+    n = lib().ora_orb_umax(_p(u))
+    return u[:n].copy()
+
+
+def orb_detect(g: np.ndarray, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20, pyramid=False):
+    """cv::ORB::detectAndCompute; returns (kps, desc[, levels, blurred levels])."""
+    g = np.ascontiguousarray(g)
+    h, w = g.shape
+    cap = 2 * nfeatures + 4096
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    lw, lh, _ = orb_levels(w, h, scale_factor, nlevels)
+    tot = int((lw.astype(np.int64) * lh).sum())
+    pyr = np.zeros(tot, np.uint8) if pyramid else None
+    blr = np.zeros(tot, np.uint8) if pyramid else None
+    n = lib().ora_orb_detect(_p(g), w, h, w, nfeatures, scale_factor, nlevels, fast_threshold, _p(kps),
+                             _p(desc), cap, _p(pyr) if pyramid else None, _p(blr) if pyramid else None)
+    assert 0 <= n <= cap
+    if not pyramid:
+        return kps[:n].copy(), desc[:n].copy()
+    lv, bl, off = [], [], 0
+    for a, b in zip(lw, lh):
+        lv.append(pyr[off:off + a * b].reshape(b, a))
+        bl.append(blr[off:off + a * b].reshape(b, a))
+        off += a * b
+    return kps[:n].copy(), desc[:n].copy(), lv, bl
 
 
 def knn2(q: np.ndarray, t: np.ndarray) -> np.ndarray:

@@ -11,8 +11,11 @@ class OracleStream:
     """One camera stream: keeps the previous features and track ages."""
 
     def __init__(self, camera=None, max_features=1000, fast_threshold=20, ratio=0.7,
-                 pnp_iters=100, pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False):
+                 pnp_iters=100, pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False, orb_levels=0,
+                 orb_scale_factor=1.2, feature_cap=None):
         self.cross_check = cross_check
+        self.orb = (orb_levels, orb_scale_factor)
+        self.feature_cap = feature_cap
         self.camera = camera  # (fx, fy, cx, cy) or None
         self.max_features = max_features
         self.fast_threshold = fast_threshold
@@ -45,7 +48,12 @@ class OracleStream:
 
     def process(self, frame: np.ndarray, depth: np.ndarray | None = None, imu=None) -> dict:
         gray = frame if frame.ndim == 2 else O.gray(frame)
-        kps, desc = O.detect(gray, self.max_features, self.fast_threshold)
+        if self.orb[0] > 0:
+            kps, desc = O.orb_detect(gray, self.max_features, self.orb[1], self.orb[0], self.fast_threshold)
+            if self.feature_cap is not None:
+                kps, desc = kps[:self.feature_cap], desc[:self.feature_cap]
+        else:
+            kps, desc = O.detect(gray, self.max_features, self.fast_threshold)
         out = {"kps": kps, "desc": desc, "matches": np.zeros(0, O.MATCH_DTYPE), "n_ratio": 0,
                "tracked": np.zeros(0, O.MATCH_DTYPE), "valid": np.zeros(0, O.MATCH_DTYPE),
                "pts3": np.zeros((0, 3), np.float32), "pnp_success": False, "rvec": np.zeros(3),

@@ -90,6 +90,20 @@ void ora_brief(const uint8_t *blur, int w, int h, int stride,
 int ora_detect(const uint8_t *gray, int w, int h, int stride, int max_features,
                int fast_threshold, ora_kp *kps, uint8_t *desc);
 
+/* ---- full ORB detector ("mode B": cv::ORB::detectAndCompute as configured
+ * at reference src/feature_detector.cpp:18-22; never executed there) -------- */
+int ora_orb_level_sizes(int w, int h, float scale_factor, int nlevels, int *lw, int *lh, float *lscale);
+void ora_orb_quotas(int nfeatures, float scale_factor, int nlevels, int *quota);
+void ora_resize_linear_exact(const uint8_t *src, int sw, int sh, int sstride, uint8_t *dst, int dw, int dh,
+                             int dstride);
+float ora_fast_atan2(float y, float x);
+float ora_harris_response(const uint8_t *img, int stride, int x0, int y0);
+int ora_orb_umax(int *umax);
+float ora_ic_angle(const uint8_t *img, int stride, int x0, int y0);
+int ora_orb_detect(const uint8_t *gray, int w, int h, int stride, int nfeatures, float scale_factor,
+                   int nlevels, int fast_threshold, ora_kp *kps, uint8_t *desc, int cap, uint8_t *pyr_out,
+                   uint8_t *blur_out);
+
 /* ---- ImageProcessor (reference src/image_processor.cpp:41-79) ---------- */
 
 /* cv::equalizeHist */

@@ -325,3 +325,97 @@ def test_gaussian_taps_and_equalize_hist(oracle):
     cum = np.cumsum(np.where(np.arange(256) > i0, hist, 0)).astype(np.float32)
     lut = np.clip(np.rint(cum * scale), 0, 255).astype(np.uint8)
     assert np.array_equal(oracle.equalize_hist(img), lut[img])
+
+
+def test_orb_geometry_and_quotas(oracle):
+    lw, lh, ls = oracle.orb_levels(1280, 720)
+    assert list(lw) == [1280, 1067, 889, 741, 617, 514, 429, 357]
+    assert list(lh) == [720, 600, 500, 417, 347, 289, 241, 201]
+    assert ls[1] == np.float32(1.2) and abs(ls[7] - 1.2 ** 7) < 1e-5
+    q = oracle.orb_quotas(2000)
+    assert list(q) == [434, 362, 302, 251, 209, 175, 145, 122] and q.sum() == 2000
+    assert list(oracle.orb_umax()) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+def test_resize_linear_exact_semantics(oracle):
+    rng = np.random.default_rng(11)
+    g = rng.integers(0, 256, (60, 90), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear_exact(g, 90, 60), g)  # identity
+    # exact 2:1 reduction samples the centre of each 2x2 block: the rounded mean
+    half = oracle.resize_linear_exact(g, 45, 30)
+    blk = g.reshape(30, 2, 45, 2).astype(np.int32).sum((1, 3))
+    assert np.array_equal(half, ((blk * 16384 + 32768) >> 16).astype(np.uint8))
+    # general ratio: within one grey level of float bilinear interpolation at (d + 0.5) * s - 0.5
+    out = oracle.resize_linear_exact(g, 75, 50).astype(np.float64)
+    sx, sy = 90 / 75, 60 / 50
+    xs = np.clip((np.arange(75) + 0.5) * sx - 0.5, 0, 89); ys = np.clip((np.arange(50) + 0.5) * sy - 0.5, 0, 59)
+    x0 = np.minimum(np.floor(xs).astype(int), 88); y0 = np.minimum(np.floor(ys).astype(int), 58)
+    fx, fy = xs - x0, ys - y0
+    gf = g.astype(np.float64)
+    ref = ((1 - fy)[:, None] * ((1 - fx) * gf[y0][:, x0] + fx * gf[y0][:, x0 + 1]) +
+           fy[:, None] * ((1 - fx) * gf[y0 + 1][:, x0] + fx * gf[y0 + 1][:, x0 + 1]))
+    assert np.abs(out - ref).max() <= 1.0
+    # constant images stay constant
+    assert (oracle.resize_linear_exact(np.full((33, 47), 201, np.uint8), 39, 28) == 201).all()
+
+
+def test_fast_atan2_and_ic_angle(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(500):
+        y, x = rng.normal(size=2) * 1000
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        d = abs(oracle.fast_atan2(y, x) - ref)
+        assert min(d, 360 - d) < 0.02
+    assert oracle.fast_atan2(0.0, 1.0) == 0.0 and oracle.fast_atan2(1.0, 0.0) == 90.0
+    # intensity centroid: a horizontal ramp points along +x, rotating the patch by 90 degrees turns the angle
+    ramp = np.tile(np.arange(64, dtype=np.uint8) * 3, (64, 1))
+    assert oracle.ic_angle(ramp, 32, 32) == 0.0
+    assert abs(oracle.ic_angle(np.ascontiguousarray(ramp.T), 32, 32) - 90.0) < 1e-3
+    assert abs(oracle.ic_angle(np.ascontiguousarray(ramp[:, ::-1]), 31, 32) - 180.0) < 1e-3
+    # brute-force moments over the disc x^2 + y^2 <= 15.5^2-ish (the umax table)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    um = oracle.orb_umax()
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        for u in range(-um[abs(v)], um[abs(v)] + 1):
+            m10 += u * int(img[32 + v, 32 + u]); m01 += v * int(img[32 + v, 32 + u])
+    assert oracle.ic_angle(img, 32, 32) == oracle.fast_atan2(float(m01), float(m10))
+
+
+def test_harris_response_against_numpy(oracle):
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (40, 40), dtype=np.uint8)
+    I = img.astype(np.int64)
+    for (x, y) in ((20, 20), (10, 25), (30, 9)):
+        a = b = c = 0
+        for yy in range(y - 3, y + 4):
+            for xx in range(x - 3, x + 4):
+                ix = 2 * (I[yy, xx + 1] - I[yy, xx - 1]) + (I[yy - 1, xx + 1] - I[yy - 1, xx - 1]) + \
+                    (I[yy + 1, xx + 1] - I[yy + 1, xx - 1])
+                iy = 2 * (I[yy + 1, xx] - I[yy - 1, xx]) + (I[yy + 1, xx - 1] - I[yy - 1, xx - 1]) + \
+                    (I[yy + 1, xx + 1] - I[yy - 1, xx + 1])
+                a += ix * ix; b += iy * iy; c += ix * iy
+        ref = (float(a) * b - float(c) * c - 0.04 * float(a + b) ** 2) * (1.0 / (4 * 7 * 255.0)) ** 4
+        assert abs(oracle.harris_response(img, x, y) - ref) <= 1e-4 * abs(ref)
+
+
+def test_orb_detect_structure(oracle, vga_seq):
+    g = oracle.gray(vga_seq["frames"][0][..., :3]) if vga_seq["frames"][0].ndim == 3 else vga_seq["frames"][0]
+    k, d = oracle.orb_detect(g, 1000)
+    q = oracle.orb_quotas(1000)
+    cnt = np.bincount(k["octave"], minlength=8)
+    assert (cnt >= np.minimum(q, cnt)).all() and (cnt <= q + 8).all() and cnt.sum() >= 900
+    _, _, ls = oracle.orb_levels(g.shape[1], g.shape[0])
+    assert np.array_equal(k["size"], (31 * ls[k["octave"]]).astype(np.float32))
+    assert (k["angle"] >= 0).all() and (k["angle"] <= 360).all()
+    # level by level, raster order inside a level
+    for l in range(8):
+        kk = k[k["octave"] == l]
+        ras = np.rint(kk["y"] / ls[l]).astype(np.int64) * 10000 + np.rint(kk["x"] / ls[l]).astype(np.int64)
+        assert (np.diff(ras) > 0).all()
+    assert (np.diff(k["octave"]) >= 0).all()
+    # descriptors of a frame and of its slightly moved successor still match
+    g1 = oracle.gray(vga_seq["frames"][1][..., :3]) if vga_seq["frames"][1].ndim == 3 else vga_seq["frames"][1]
+    k1, d1 = oracle.orb_detect(g1, 1000)
+    m, _, nr = oracle.match_filter(oracle.knn2(d, d1), len(k1), k, k1, 0.7)
+    assert len(m) > 200

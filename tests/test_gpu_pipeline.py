@@ -131,3 +131,27 @@ def test_batch_pipeline_cross_check(ctx, oracle):
     res = ctx.batch_wait()
     for f in range(4):
         _compare_frame(ctx, res, f, ref.process(seq["frames"][f], seq["depth"][f]), pose=True)
+
+
+def test_batch_pipeline_full_orb(ctx, oracle):
+    """The batched pipeline with the full ORB detector (8-level pyramid) in front."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F = 2, 2
+    seqs = [synth.make_sequence(cam, 2 * F, seed=8800 + s, channels=4) for s in range(S)]
+    refs = [OracleStream(K, 1500, 20, orb_levels=8, feature_cap=ctx.max_features) for _ in range(S)]
+    ctx.batch_configure(cam.width, cam.height, 4, n_streams=S, frames_per_stream=F, max_features=1500,
+                        camera=K, orb_levels=8)
+    for nb in range(2):
+        frames = np.stack([seqs[s]["frames"][nb * F + f] for s in range(S) for f in range(F)])
+        depth = np.stack([seqs[s]["depth"][nb * F + f] for s in range(S) for f in range(F)])
+        ctx.batch_submit(frames, depth)
+        res = ctx.batch_wait()
+        for s in range(S):
+            for f in range(F):
+                ref = refs[s].process(seqs[s]["frames"][nb * F + f], seqs[s]["depth"][nb * F + f])
+                _compare_frame(ctx, res, s * F + f, ref, pose=True)
+                assert len(np.unique(ref["kps"]["octave"])) == 8
+                if nb or f:
+                    assert ref["pnp_success"] and len(ref["matches"]) > 100

@@ -39,7 +39,8 @@ class VoBatchCfg(C.Structure):
                 ("f_threshold", C.c_double), ("f_confidence", C.c_double), ("f_max_iters", C.c_int),
                 ("enable_pose", C.c_int), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
                 ("cy", C.c_double), ("pnp_iters", C.c_int), ("pnp_threshold", C.c_double),
-                ("pnp_confidence", C.c_double), ("cross_check", C.c_int)]
+                ("pnp_confidence", C.c_double), ("cross_check", C.c_int),
+                ("orb_levels", C.c_int), ("orb_scale_factor", C.c_float)]
 
 
 RESULT_DTYPE = np.dtype([("n_keypoints", "<i4"), ("n_ratio", "<i4"), ("f_found", "<i4"),
@@ -70,6 +71,9 @@ EXPORTS = {
     "vo_find_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                              _P, _P, _P, _P]),
     "vo_match_features": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P]),
+    "vo_detect_orb": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P,
+                                C.c_int, _P]),
+    "vo_orb_get_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, _P, _P, _P, _P, C.c_int]),
     "vo_match_features_ex": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P]),
@@ -196,6 +200,26 @@ class Context:
             C.addressof(found), C.addressof(iters)))
         return bool(found.value), F.reshape(3, 3), mask[:n].copy(), iters.value
 
+    def detect_orb(self, gray: np.ndarray, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20,
+                   cap=None):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        cap = cap or self.max_features
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        self._check(self._lib.vo_detect_orb(self._h, _ptr(gray), w, h, w, nfeatures, scale_factor, nlevels,
+                                            fast_threshold, _ptr(kps), _ptr(desc), cap, C.addressof(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def orb_level(self, frame: int, level: int, blurred=False) -> np.ndarray:
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self._lib.vo_orb_get_level(self._h, frame, level, int(blurred), None, 0, C.addressof(w),
+                                               C.addressof(h)))
+        out = np.empty((h.value, w.value), np.uint8)
+        self._check(self._lib.vo_orb_get_level(self._h, frame, level, int(blurred), _ptr(out), w.value, None, None))
+        return out
+
     def process_image(self, img: np.ndarray, enhance=False, blur_size=3, sigma=1.0, hist_eq=False) -> dict:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape[:2]
@@ -236,13 +260,14 @@ class Context:
     def batch_configure(self, width, height, channels, n_streams=1, frames_per_stream=1,
                         max_features=1000, fast_threshold=20, ratio=0.7, f_threshold=3.0,
                         f_confidence=0.99, f_max_iters=1000, camera=None, pnp_iters=100,
-                        pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False):
+                        pnp_threshold=8.0, pnp_confidence=0.99, cross_check=False, orb_levels=0,
+                        orb_scale_factor=1.2):
         """camera: (fx, fy, cx, cy) enables depth back-projection + PnP."""
         fx, fy, cx, cy = camera if camera is not None else (0.0, 0.0, 0.0, 0.0)
         cfg = VoBatchCfg(width, height, channels, n_streams, frames_per_stream, max_features,
                          fast_threshold, ratio, f_threshold, f_confidence, f_max_iters,
                          1 if camera is not None else 0, fx, fy, cx, cy, pnp_iters, pnp_threshold,
-                         pnp_confidence, int(cross_check))
+                         pnp_confidence, int(cross_check), orb_levels, orb_scale_factor)
         self._check(self._lib.vo_batch_configure(self._h, C.byref(cfg)))
         self._bcfg = cfg
         self._batch = n_streams * frames_per_stream

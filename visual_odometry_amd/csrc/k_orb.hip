@@ -1,0 +1,495 @@
+// Full ORB detector kernels for gfx950 (pyramid, per-level Harris ranking,
+// intensity-centroid orientation, steered rBRIEF): what
+// cv::ORB::create(nfeatures, scaleFactor, nlevels)->detectAndCompute() computes
+// for the object the reference builds at src/feature_detector.cpp:18-22.
+// The per-level FAST + NMS + Gaussian stage is the fused tile kernel of
+// k_image.hip, run once per level.
+//
+// Integer stages are bit-exact by construction; the Harris response, the
+// orientation and the pattern rotation are float32 expressions evaluated in
+// OpenCV's order (the library is built with -ffp-contract=off).
+#include <float.h>
+
+#include "vo_internal.h"
+
+namespace vo {
+
+namespace {
+
+// ------------------------------------------------------------------ resize
+
+constexpr int RZ_TW = 128, RZ_TH = 16, RZ_THREADS = 256;
+constexpr int RZ_FP = 272;    // LDS footprint row pitch (bytes): scale <= 2 plus alignment slack
+constexpr int RZ_FROWS = 36;  // footprint rows
+
+// One axis entry of cv::resize(INTER_LINEAR_EXACT): source offset and the 8.8
+// weight of the second tap; scale = 1 / (dst/src) in double, sample position
+// scale * (d + 0.5) - 0.5, replicate outside [0, src-1).
+__device__ __forceinline__ void rz_axis(int d, int src_n, int dst_n, int &ofs, int &w1)
+{
+    const double inv_scale = (double)dst_n / (double)src_n;
+    const double scale = 1.0 / inv_scale;
+    const double f = scale * ((double)d + 0.5) - 0.5;
+    const int i = (int)floor(f);
+    if (i >= 0 && src_n > 1) {
+        if (i < src_n - 1) {
+            ofs = i;
+            w1 = (int)rint((f - (double)i) * 256.0);
+        } else {
+            ofs = src_n - 1;
+            w1 = 0;
+        }
+    } else {
+        ofs = 0;
+        w1 = 0;
+    }
+}
+
+// Level l from level l-1 for every frame of the batch.  One 128x16 output tile
+// per block; the source footprint is staged in LDS with dword loads.
+__global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
+                                                            int dh)
+{
+    __shared__ int s_xo[RZ_TW], s_xw[RZ_TW], s_yo[RZ_TH], s_yw[RZ_TH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * RZ_TW, y0 = blockIdx.y * RZ_TH, f = blockIdx.z;
+    if (tid < RZ_TW) {
+        int o, w;
+        rz_axis(min(x0 + tid, dw - 1), sw, dw, o, w);
+        s_xo[tid] = o;
+        s_xw[tid] = w;
+    } else if (tid < RZ_TW + RZ_TH) {
+        int o, w;
+        rz_axis(min(y0 + tid - RZ_TW, dh - 1), sh, dh, o, w);
+        s_yo[tid - RZ_TW] = o;
+        s_yw[tid - RZ_TW] = w;
+    }
+    __syncthreads();
+    const int sx_lo = s_xo[0] & ~3, sx_hi = min(s_xo[RZ_TW - 1] + 1, sw - 1);
+    const int sy_lo = s_yo[0], sy_hi = min(s_yo[RZ_TH - 1] + 1, sh - 1);
+    const int cols4 = (sx_hi - sx_lo) / 4 + 1, rows = sy_hi - sy_lo + 1;  // host checked: fits the LDS footprint
+    const uint8_t *sp = src.base + f * src.plane_stride;
+    for (int i = tid; i < rows * cols4; i += RZ_THREADS) {
+        const int r = i / cols4, c4 = i - r * cols4;
+        *reinterpret_cast<uint32_t *>(&s_src[r * RZ_FP + c4 * 4]) =
+            *reinterpret_cast<const uint32_t *>(sp + (size_t)(sy_lo + r) * src.pitch + sx_lo + c4 * 4);
+    }
+    __syncthreads();
+
+    uint8_t *dp = dst.base + f * dst.plane_stride;
+    for (int q = tid; q < RZ_TW * RZ_TH / 4; q += RZ_THREADS) {
+        const int ly = q / (RZ_TW / 4), lx = (q - ly * (RZ_TW / 4)) * 4;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (gy >= dh || gx >= dw) continue;
+        const int yo = s_yo[ly];
+        const uint8_t *r0 = &s_src[(yo - sy_lo) * RZ_FP];
+        const uint8_t *r1 = &s_src[(min(yo + 1, sh - 1) - sy_lo) * RZ_FP];
+        const uint32_t wy1 = (uint32_t)s_yw[ly], wy0 = 256u - wy1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int xo = s_xo[lx + j];
+            const int a = xo - sx_lo, b = min(xo + 1, sw - 1) - sx_lo;
+            const uint32_t wx1 = (uint32_t)s_xw[lx + j], wx0 = 256u - wx1;
+            const uint32_t h0 = wx0 * r0[a] + wx1 * r0[b];
+            const uint32_t h1 = wx0 * r1[a] + wx1 * r1[b];
+            out |= ((wy0 * h0 + wy1 * h1 + 32768u) >> 16) << (8 * j);
+        }
+        *reinterpret_cast<uint32_t *>(dp + (size_t)gy * dst.pitch + gx) = out;  // pitch is padded
+    }
+}
+
+// ------------------------------------------------- per-level keypoint ranking
+
+constexpr int OS_THREADS = 1024;
+constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level
+
+// HarrisResponses(): 7x7 block, k = 0.04, Sobel-like integer gradients
+__device__ __forceinline__ float harris_response(const uint8_t *img, int pitch, int x0, int y0)
+{
+    // rows y0-4 .. y0+4, columns x0-4 .. x0+4; gradients need a sliding 3-row window
+    int a = 0, b = 0, c = 0;
+    const uint8_t *base = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+    int up[9], mid[9], dn[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { up[j] = base[j]; mid[j] = base[pitch + j]; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const uint8_t *row = base + (size_t)(i + 2) * pitch;
+#pragma unroll
+        for (int j = 0; j < 9; j++) dn[j] = row[j];
+#pragma unroll
+        for (int j = 1; j <= 7; j++) {
+            const int ix = (mid[j + 1] - mid[j - 1]) * 2 + (up[j + 1] - up[j - 1]) + (dn[j + 1] - dn[j - 1]);
+            const int iy = (dn[j] - up[j]) * 2 + (dn[j - 1] - up[j - 1]) + (dn[j + 1] - up[j + 1]);
+            a += ix * ix;
+            b += iy * iy;
+            c += ix * iy;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) { up[j] = mid[j]; mid[j] = dn[j]; }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    const float fa = (float)a, fb = (float)b, fc = (float)c;
+    return (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+}
+
+// float -> unsigned key with the same order
+__device__ __forceinline__ uint32_t ordered_key(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// One block per (level, frame): what computeKeyPoints() does to the FAST
+// corners of one pyramid level --
+//   runByImageBorder(31) -> retainBest(2*quota) by FAST score ->
+//   Harris response -> retainBest(quota) by Harris response --
+// where retainBest(n) keeps every keypoint whose response is >= the n-th
+// largest (all boundary ties survive).  OpenCV leaves the survivors in
+// nth_element order (unspecified); here they are written in raster order.
+__global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, const uint8_t *__restrict__ pyr,
+                                                          const uint32_t *__restrict__ cand,
+                                                          const uint32_t *__restrict__ cand_count,
+                                                          uint32_t *__restrict__ lvl_ras,
+                                                          float *__restrict__ lvl_resp, int *__restrict__ lvl_n)
+{
+    __shared__ uint32_t s_ras[OS_K1CAP];
+    __shared__ uint32_t s_key[OS_K1CAP];
+    __shared__ uint32_t s_oras[kOrbLevelCap];
+    __shared__ uint32_t s_okey[kOrbLevelCap];
+    __shared__ uint32_t s_hist[256];
+    __shared__ int s_cut, s_n1, s_n2, s_remaining;
+    __shared__ uint32_t s_prefix;
+
+    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const OrbLevel L = plan.lv[l];
+    const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
+    const uint32_t *c = cand + L.cand_off + (size_t)f * L.cand_cap;
+    const int M = min((int)cand_count[l * batch + f], L.cand_cap);
+    const uint8_t *img = pyr + (size_t)f * plan.frame_bytes + L.off;
+    const bool size_ok = w > 2 * border && h > 2 * border && quota > 0;
+
+    for (int i = tid; i < 256; i += OS_THREADS) s_hist[i] = 0;
+    if (tid == 0) { s_n1 = 0; s_n2 = 0; s_cut = -1; }
+    __syncthreads();
+
+    // 1. border filter + FAST-score histogram
+    auto in_border = [&](uint32_t ras) {
+        const int y = ras / (uint32_t)w, x = ras - y * w;
+        return x >= border && x < w - border && y >= border && y < h - border;
+    };
+    if (size_ok)
+        for (int i = tid; i < M; i += OS_THREADS) {
+            const uint32_t k = c[i];
+            if (in_border(k & 0xffffffu)) atomicAdd(&s_hist[k >> 24], 1u);
+        }
+    __syncthreads();
+    if (tid == 0 && size_ok) {
+        // bins are 255 - score: walk from the best score down until 2*quota corners are covered
+        int cum = 0, b = 0;
+        for (; b < 256; b++) {
+            cum += (int)s_hist[b];
+            if (cum >= 2 * quota) break;
+        }
+        s_cut = min(b, 255);  // every bin <= cut survives (all of them when fewer than 2*quota exist)
+    }
+    __syncthreads();
+
+    // 2. gather the survivors
+    const int cut = s_cut;
+    if (cut >= 0)
+        for (int i = tid; i < M; i += OS_THREADS) {
+            const uint32_t k = c[i];
+            if ((int)(k >> 24) <= cut && in_border(k & 0xffffffu)) {
+                const int slot = atomicAdd(&s_n1, 1);
+                if (slot < OS_K1CAP) s_ras[slot] = k & 0xffffffu;
+            }
+        }
+    __syncthreads();
+    const int K1 = min(s_n1, OS_K1CAP);
+
+    // 3. Harris response of each survivor
+    for (int i = tid; i < K1; i += OS_THREADS) {
+        const uint32_t ras = s_ras[i];
+        const int y = ras / (uint32_t)w, x = ras - y * w;
+        s_key[i] = ordered_key(harris_response(img, L.pitch, x, y));
+    }
+    __syncthreads();
+
+    // 4. the quota-th largest key by an MSB-first radix select
+    uint32_t threshold = 0;
+    if (K1 > quota) {
+        if (tid == 0) { s_prefix = 0; s_remaining = quota; }
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += OS_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (int i = tid; i < K1; i += OS_THREADS) {
+                const uint32_t k = s_key[i];
+                if ((k & hi_mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int rem = s_remaining, d = 255;
+                for (; d > 0; d--) {
+                    if ((int)s_hist[d] >= rem) break;
+                    rem -= (int)s_hist[d];
+                }
+                s_remaining = rem;
+                s_prefix = prefix | ((uint32_t)d << shift);
+            }
+            __syncthreads();
+        }
+        threshold = s_prefix;
+    }
+
+    // 5. survivors of the second cut, sorted by raster index
+    for (int i = tid; i < K1; i += OS_THREADS) {
+        if (s_key[i] >= threshold) {
+            const int slot = atomicAdd(&s_n2, 1);
+            if (slot < kOrbLevelCap) { s_oras[slot] = s_ras[i]; s_okey[slot] = s_key[i]; }
+        }
+    }
+    __syncthreads();
+    const int K2 = min(s_n2, kOrbLevelCap);
+    int n_pow2 = 1;
+    while (n_pow2 < K2) n_pow2 <<= 1;
+    for (int i = K2 + tid; i < n_pow2; i += OS_THREADS) s_oras[i] = 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < n_pow2 / 2; t += OS_THREADS) {
+                const int i = ((t / j) * 2 * j) + (t % j), p = i + j;
+                const bool up = (i & k) == 0;
+                const uint32_t a = s_oras[i], b = s_oras[p];
+                if ((a > b) == up) {
+                    s_oras[i] = b; s_oras[p] = a;
+                    const uint32_t ka = s_okey[i];
+                    s_okey[i] = s_okey[p]; s_okey[p] = ka;
+                }
+            }
+            __syncthreads();
+        }
+    const size_t o = ((size_t)f * plan.nlevels + l) * kOrbLevelCap;
+    for (int i = tid; i < K2; i += OS_THREADS) {
+        lvl_ras[o + i] = s_oras[i];
+        lvl_resp[o + i] = key_to_float(s_okey[i]);
+    }
+    if (tid == 0) lvl_n[f * plan.nlevels + l] = K2;
+}
+
+// -------------------------------------------------- orientation + keypoints
+
+__device__ const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// cv::fastAtan2, scalar path (degrees)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+constexpr int OF_THREADS = 256;
+
+// One wave per output keypoint: concatenates the levels' survivors (level by
+// level), computes the intensity-centroid angle over the radius-15 disc of
+// the keypoint's level image (ICAngles()) and writes the cv::KeyPoint with
+// pt scaled to level-0 coordinates, size = 31 * scale, octave = level.
+// Lanes 0..30 / 32..62 own the 31 columns u = -15..15 of the even / odd rows.
+__global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const uint8_t *__restrict__ pyr,
+                                                          const uint32_t *__restrict__ lvl_ras,
+                                                          const float *__restrict__ lvl_resp,
+                                                          const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
+                                                          int kp_stride, int *__restrict__ nkp)
+{
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (OF_THREADS / 64) + (threadIdx.x >> 6);
+    int level = -1, j = 0, total = 0;
+    for (int l = 0; l < plan.nlevels; l++) {
+        const int n = lvl_n[f * plan.nlevels + l];
+        if (level < 0 && i < total + n) { level = l; j = i - total; }
+        total += n;
+    }
+    total = min(total, kp_stride);
+    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[f] = total;
+    if (level < 0 || i >= total) return;
+
+    const OrbLevel L = plan.lv[level];
+    const size_t o = ((size_t)f * plan.nlevels + level) * kOrbLevelCap + j;
+    const uint32_t ras = lvl_ras[o];
+    const int y = ras / (uint32_t)L.w, x = ras - y * L.w;
+    const uint8_t *center = pyr + (size_t)f * plan.frame_bytes + L.off + (size_t)y * L.pitch + x;
+
+    const int u = (lane & 31) - 15, half = lane >> 5;
+    int m10 = 0, m01 = 0;
+    if (u <= 15) {
+        for (int v = -15 + half; v <= 15; v += 2) {
+            if (abs(u) <= kUmax[abs(v)]) {
+                const int val = center[v * L.pitch + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    if (lane == 0) {
+        vo_kp kp;
+        kp.x = (float)x * L.scale;
+        kp.y = (float)y * L.scale;
+        kp.size = 31 * L.scale;
+        kp.angle = fast_atan2_deg((float)m01, (float)m10);
+        kp.response = lvl_resp[o];
+        kp.octave = level;
+        kps[(size_t)f * kp_stride + i] = kp;
+    }
+}
+
+// ------------------------------------------------------------ steered BRIEF
+
+// 32 lanes per keypoint, one descriptor byte per lane: computeOrbDescriptors()
+// with WTA_K = 2 on the blurred level image of the keypoint's octave, the
+// 31x31 pattern rotated by the keypoint angle per sample (float32, cvRound).
+__global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8_t *__restrict__ pyr_blur,
+                                                      const vo_kp *__restrict__ kps, int kp_stride,
+                                                      const int *__restrict__ nkp,
+                                                      const int8_t *__restrict__ pattern,
+                                                      uint8_t *__restrict__ desc)
+{
+    __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
+    reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int byte = threadIdx.x & 31;
+    if (k >= nkp[f]) return;
+    const vo_kp kp = kps[(size_t)f * kp_stride + k];
+    const OrbLevel L = plan.lv[kp.octave];
+    const float inv = 1.f / L.scale;
+    float angle = kp.angle;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int pitch = L.pitch;
+    const uint8_t *center = pyr_blur + (size_t)f * plan.frame_bytes + L.off +
+                            (size_t)__float2int_rn(kp.y * inv) * pitch + __float2int_rn(kp.x * inv);
+    const int8_t *p = s_pat + byte * 32;
+    uint32_t val = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const float x0 = (float)p[4 * t + 0], y0 = (float)p[4 * t + 1];
+        const float x1 = (float)p[4 * t + 2], y1 = (float)p[4 * t + 3];
+        const int ix0 = __float2int_rn(x0 * a - y0 * b), iy0 = __float2int_rn(x0 * b + y0 * a);
+        const int ix1 = __float2int_rn(x1 * a - y1 * b), iy1 = __float2int_rn(x1 * b + y1 * a);
+        const int t0 = center[iy0 * pitch + ix0];
+        const int t1 = center[iy1 * pitch + ix1];
+        val |= (uint32_t)(t0 < t1) << t;
+    }
+    desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
+}
+
+}  // namespace
+
+// level geometry and quotas exactly as ORB derives them:
+// scale_l = float(pow(double(scaleFactor), l)), size_l = cvRound(size / scale_l),
+// quota_l = cvRound(N (1-f) / (1-f^L) f^l) with f = float(1/scaleFactor), the
+// last level taking the remainder.
+bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch, OrbPlan *out)
+{
+    if (nlevels < 1 || nlevels > kOrbMaxLevels || !(scale_factor > 1.f) || scale_factor > 2.f) return false;
+    OrbPlan p{};
+    p.nlevels = nlevels;
+    const float factor = (float)(1.0 / scale_factor);
+    float per = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    size_t off = 0, coff = 0;
+    for (int l = 0; l < nlevels; l++) {
+        OrbLevel &L = p.lv[l];
+        L.scale = (float)pow((double)scale_factor, (double)l);
+        L.w = (int)lrintf((float)w / L.scale);
+        L.h = (int)lrintf((float)h / L.scale);
+        if (L.w < 7 || L.h < 7) return false;
+        L.pitch = (L.w + 127) / 128 * 128;
+        L.off = off;
+        off += (size_t)L.pitch * ((L.h + 15) / 16 * 16);
+        if (l < nlevels - 1) {
+            L.quota = (int)lrintf(per);
+            sum += L.quota;
+            per *= factor;
+        } else {
+            L.quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
+        }
+        if (L.quota > kOrbLevelCap - 256 || 2 * L.quota + 512 > OS_K1CAP) return false;
+        L.cand_cap = L.w * L.h / 4 + 64;
+        L.cand_off = coff;
+        coff += (size_t)L.cand_cap * batch;
+        if (l > 0) {
+            // the resize kernel's LDS footprint of one 128x16 output tile
+            const OrbLevel &S = p.lv[l - 1];
+            const double sx = (double)S.w / L.w, sy = (double)S.h / L.h;
+            if (RZ_TW * sx + 8 > RZ_FP || RZ_TH * sy + 3 > RZ_FROWS) return false;
+        }
+    }
+    p.frame_bytes = off;
+    p.cand_total = coff;
+    *out = p;
+    return true;
+}
+
+void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, int batch, hipStream_t s)
+{
+    dim3 grid((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, batch);
+    hipLaunchKernelGGL(k_resize_exact, grid, dim3(RZ_THREADS), 0, s, src, sw, sh, dst, dw, dh);
+}
+
+void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
+                       const uint32_t *cand_count, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_orb_select, dim3(plan.nlevels, batch), dim3(OS_THREADS), 0, s, plan, batch, pyr, cand,
+                       cand_count, lvl_ras, lvl_resp, lvl_n);
+}
+
+void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
+                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s)
+{
+    dim3 grid((kp_stride + OF_THREADS / 64 - 1) / (OF_THREADS / 64), batch);
+    hipLaunchKernelGGL(k_orb_finish, grid, dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras, lvl_resp, lvl_n, kps,
+                       kp_stride, nkp);
+}
+
+void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
+                          const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s)
+{
+    dim3 grid((kp_stride + 7) / 8, batch);
+    hipLaunchKernelGGL(k_brief_steered, grid, dim3(256), 0, s, plan, pyr_blur, kps, kp_stride, nkp, pattern, desc);
+}
+
+}  // namespace vo

@@ -96,6 +96,11 @@ int vo_batch_configure(vo_ctx *c, const vo_batch_cfg *b)
         return bfail(c, VO_ERR_ARG, "vo_batch_configure: pose needs fx, fy > 0");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (b->orb_levels > 0) {
+        const int rc = c->ensure_orb(b->width, b->height, b->orb_scale_factor > 0 ? b->orb_scale_factor : 1.2f,
+                                     b->orb_levels, b->max_features, b->n_streams * b->frames_per_stream);
+        if (rc) return rc;
+    }
     c->bcfg = *b;
     c->configured = true;
     c->submitted = false;
@@ -178,8 +183,16 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
     }
     if (!b.enable_pose) dsrc = nullptr;
 
-    c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
-                      b.fast_threshold, B, /*first_slot=*/S);
+    if (b.orb_levels > 0) {
+        // a single-frame ORB operator call may have re-planned the pyramid since configure
+        const int rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f,
+                                     b.orb_levels, b.max_features, B);
+        if (rc) return rc;
+        c->enqueue_detect_orb(src, b.width, b.height, row_stride, frame_stride, b.channels, b.fast_threshold, B,
+                              /*first_slot=*/S);
+    } else
+        c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
+                          b.fast_threshold, B, /*first_slot=*/S);
     c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
     c->mark(6);
     launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -178,6 +179,8 @@ int vo_ctx::allocate()
     int8_t pat[1024];
     build_pattern(-1.0f, pat);
     HIP_TRY(ctx, hipMemcpy(d_pattern, pat, 1024, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(&d_pattern0, 1024));
+    HIP_TRY(ctx, hipMemcpy(d_pattern0, vo_orb_bit_pattern_31, 1024, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipHostMalloc(&h_pinned, kPinnedBytes));
     return VO_OK;
 }
@@ -185,7 +188,8 @@ int vo_ctx::allocate()
 void vo_ctx::release()
 {
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_count, d_kps, d_desc, d_nkp, d_pattern,
-                    d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist,
+                    d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0,
+                    d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results};
     for (void *p : ptrs)
@@ -385,6 +389,47 @@ static int set_single_pair(vo_ctx *c)
     return VO_OK;
 }
 
+int vo_detect_orb(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int nfeatures, float scale_factor,
+                  int nlevels, int fast_threshold, vo_kp *kps, uint8_t *desc, int cap, int *n_out)
+{
+    int rc = check_frame(c, w, h, "vo_detect_orb");
+    if (rc) return rc;
+    if (!gray || !kps || !desc || !n_out || stride < w || nfeatures < 1 || nfeatures > c->cfg.max_features || cap < 1)
+        return fail(c, VO_ERR_ARG, "vo_detect_orb: bad arguments (nfeatures %d, context limit %d)", nfeatures,
+                    c->cfg.max_features);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = c->ensure_orb(w, h, scale_factor, nlevels, nfeatures, 1))) return rc;
+    if ((rc = stage_image(c, gray, w, h, stride))) return rc;
+    c->enqueue_detect_orb(c->d_in, w, h, w, 0, 1, fast_threshold, 1, c->op_slot0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_nkp + c->op_slot0, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = finish(c, "vo_detect_orb"))) return rc;
+    const int n = std::min(*reinterpret_cast<int *>(c->h_pinned), cap);
+    *n_out = n;
+    if (n > 0) {
+        HIP_TRY(c, hipMemcpy(kps, c->d_kps + (size_t)c->op_slot0 * c->kp_stride, sizeof(vo_kp) * n, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(desc, c->d_desc + (size_t)c->op_slot0 * c->kp_stride * 32, (size_t)32 * n, hipMemcpyDefault));
+    }
+    return VO_OK;
+}
+
+int vo_orb_get_level(vo_ctx *c, int frame, int level, int blurred, uint8_t *dst, int dst_stride, int *w_out,
+                     int *h_out)
+{
+    if (!c) return VO_ERR_ARG;
+    if (c->orb.nlevels < 1 || level < 0 || level >= c->orb.nlevels || frame < 0 || frame >= c->orb_batch)
+        return fail(c, VO_ERR_ARG, "vo_orb_get_level: no such level (run the ORB detector first)");
+    const OrbLevel &L = c->orb.lv[level];
+    if (w_out) *w_out = L.w;
+    if (h_out) *h_out = L.h;
+    if (!dst) return VO_OK;
+    if (dst_stride < L.w) return fail(c, VO_ERR_ARG, "vo_orb_get_level: stride too small");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint8_t *base = (blurred ? c->d_pyr_blur : c->d_pyr) + (size_t)frame * c->orb.frame_bytes + L.off;
+    HIP_TRY(c, hipMemcpy2D(dst, dst_stride, base, L.pitch, L.w, L.h, hipMemcpyDefault));
+    return VO_OK;
+}
+
 int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *train, int nt, vo_knn2 *out)
 {
     if (!c) return VO_ERR_ARG;
@@ -494,6 +539,80 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
     mark(2);
     launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
                  d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
+}
+
+int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch)
+{
+    vo_ctx *ctx = this;
+    if (orb.nlevels == nlevels && orb_w == w && orb_h == h && orb_scale == scale_factor &&
+        orb_features == nfeatures && orb_batch == batch)
+        return VO_OK;
+    OrbPlan p;
+    if (!orb_make_plan(w, h, scale_factor, nlevels, nfeatures, batch, &p))
+        return fail(ctx, VO_ERR_UNSUPPORTED,
+                    "ORB pyramid %dx%d, scale %.3f, %d levels, %d features is outside the supported range "
+                    "(1 < scale <= 2, 1..8 levels, smallest level >= 7 px, <= 1792 features per level)",
+                    w, h, (double)scale_factor, nlevels, nfeatures);
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    const size_t pyr_need = p.frame_bytes * batch;
+    if (pyr_need > orb_pyr_cap) {
+        if (d_pyr) (void)hipFree(d_pyr);
+        if (d_pyr_blur) (void)hipFree(d_pyr_blur);
+        d_pyr = d_pyr_blur = nullptr;
+        orb_pyr_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&d_pyr, pyr_need));
+        HIP_TRY(ctx, hipMalloc(&d_pyr_blur, pyr_need));
+        orb_pyr_cap = pyr_need;
+    }
+    if (p.cand_total > orb_cand_cap) {
+        if (d_orb_cand) (void)hipFree(d_orb_cand);
+        d_orb_cand = nullptr;
+        orb_cand_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&d_orb_cand, sizeof(uint32_t) * p.cand_total));
+        orb_cand_cap = p.cand_total;
+    }
+    const int lvl_need = batch * kOrbMaxLevels;
+    if (lvl_need > orb_lvl_cap) {
+        for (void *q : {(void *)d_orb_cand_count, (void *)d_lvl_ras, (void *)d_lvl_resp, (void *)d_lvl_n})
+            if (q) (void)hipFree(q);
+        d_orb_cand_count = d_lvl_ras = nullptr; d_lvl_resp = nullptr; d_lvl_n = nullptr;
+        orb_lvl_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&d_orb_cand_count, sizeof(uint32_t) * lvl_need));
+        HIP_TRY(ctx, hipMalloc(&d_lvl_ras, sizeof(uint32_t) * (size_t)lvl_need * kOrbLevelCap));
+        HIP_TRY(ctx, hipMalloc(&d_lvl_resp, sizeof(float) * (size_t)lvl_need * kOrbLevelCap));
+        HIP_TRY(ctx, hipMalloc(&d_lvl_n, sizeof(int) * lvl_need));
+        orb_lvl_cap = lvl_need;
+    }
+    orb = p;
+    orb_w = w; orb_h = h; orb_scale = scale_factor; orb_features = nfeatures; orb_batch = batch;
+    return VO_OK;
+}
+
+void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
+                                int channels, int fast_threshold, int batch, int first_slot)
+{
+    (void)hipMemsetAsync(d_orb_cand_count, 0, sizeof(uint32_t) * orb.nlevels * batch, stream);
+    mark(0);
+    auto level = [&](uint8_t *base, int l) { return PlaneBatch{base + orb.lv[l].off, orb.lv[l].pitch, orb.frame_bytes}; };
+    for (int l = 0; l < orb.nlevels; l++) {
+        const OrbLevel &L = orb.lv[l];
+        if (l > 0)
+            launch_resize_exact(level(d_pyr, l - 1), orb.lv[l - 1].w, orb.lv[l - 1].h, level(d_pyr, l), L.w, L.h,
+                                batch, stream);
+        // level 0 converts to gray on the way in and keeps the gray plane for the next level
+        const uint8_t *in = l == 0 ? src : d_pyr + L.off;
+        launch_frontend(in, L.w, L.h, l == 0 ? src_stride : L.pitch, l == 0 ? src_frame_stride : orb.frame_bytes,
+                        l == 0 ? channels : 1, l == 0 ? level(d_pyr, 0) : PlaneBatch{nullptr, 0, 0},
+                        PlaneBatch{nullptr, 0, 0}, level(d_pyr_blur, l), fast_threshold, d_orb_cand + L.cand_off,
+                        d_orb_cand_count + (size_t)l * batch, L.cand_cap, batch, gc, stream);
+    }
+    mark(1);
+    launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n, stream);
+    launch_orb_finish(orb, batch, d_pyr, d_lvl_ras, d_lvl_resp, d_lvl_n, d_kps + (size_t)first_slot * kp_stride,
+                      kp_stride, d_nkp + first_slot, stream);
+    mark(2);
+    launch_brief_steered(orb, batch, d_pyr_blur, d_kps + (size_t)first_slot * kp_stride, kp_stride,
+                         d_nkp + first_slot, d_pattern0, d_desc + (size_t)first_slot * kp_stride * 32, stream);
 }
 
 void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacParams prm)

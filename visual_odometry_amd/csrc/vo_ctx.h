@@ -41,6 +41,18 @@ struct vo_ctx {
     uint32_t *d_rng = nullptr;
     int rng_len = 0;
 
+    // full ORB detector (allocated on first use)
+    vo::OrbPlan orb{};
+    int orb_w = 0, orb_h = 0, orb_features = 0, orb_batch = 0;
+    float orb_scale = 0.f;
+    size_t orb_pyr_cap = 0, orb_cand_cap = 0;
+    int orb_lvl_cap = 0;
+    uint8_t *d_pyr = nullptr, *d_pyr_blur = nullptr;
+    uint32_t *d_orb_cand = nullptr, *d_orb_cand_count = nullptr, *d_lvl_ras = nullptr;
+    float *d_lvl_resp = nullptr;
+    int *d_lvl_n = nullptr;
+    int8_t *d_pattern0 = nullptr;  // the unrotated 31x31 test pattern
+
     // pose stage
     float *d_depth = nullptr;  // staging for depth handed over from the host
     int *d_ages = nullptr;     // track ages, one row per feature slot
@@ -80,6 +92,11 @@ struct vo_ctx {
     // feature slots first_slot .. first_slot+batch-1
     void enqueue_detect(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
                         int channels, int max_features, int fast_threshold, int batch, int first_slot);
+    // plan + buffers of the full ORB detector for this geometry; VO_OK or an error code
+    int ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch);
+    // the same contract as enqueue_detect, with cv::ORB::detectAndCompute semantics
+    void enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
+                            int channels, int fast_threshold, int batch, int first_slot);
     // kNN-2 + ratio + F-RANSAC + motion filter for `pairs` (d_qslot/d_tslot) pairs
     void enqueue_match(int pairs, float ratio, bool cross_check, vo::FRansacParams prm);
 };

@@ -13,6 +13,8 @@ constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
 constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
 constexpr int kKnnSplits = 4;      // train-set splits per query block
 constexpr int kFBorder = 31;       // ORB edgeThreshold
+constexpr int kOrbMaxLevels = 8;   // pyramid levels of the full ORB detector
+constexpr int kOrbLevelCap = 2048; // keypoints one level can contribute
 
 // gray conversion weights (B, G, R, shift)
 struct GrayCoeffs {
@@ -25,6 +27,41 @@ struct PlaneBatch {
     int pitch;            // bytes per row
     size_t plane_stride;  // bytes between consecutive planes
 };
+
+// One pyramid level of the full ORB detector.
+struct OrbLevel {
+    int w, h, pitch;   // level image; rows are `pitch` bytes apart
+    int quota;         // keypoints wanted from this level
+    float scale;       // level-0 pixels per level pixel
+    int cand_cap;      // FAST corners one frame can emit on this level
+    size_t off;        // byte offset of the level inside a frame's pyramid
+    size_t cand_off;   // element offset of the level's candidate lists ([frame][cand_cap])
+};
+
+// Geometry of the pyramid for one (frame size, scale factor, levels, nfeatures, batch).
+struct OrbPlan {
+    int nlevels;
+    size_t frame_bytes;  // bytes of one frame's pyramid (all levels, padded to whole tiles)
+    size_t cand_total;   // candidate-list elements for the whole batch
+    OrbLevel lv[kOrbMaxLevels];
+};
+
+// false when the configuration is outside what the kernels support
+// (1 < scale_factor <= 2, 1..8 levels, smallest level >= 7 px, quota per level <= 1792)
+bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch, OrbPlan *out);
+
+// cv::resize(INTER_LINEAR_EXACT) of every plane of `src` into `dst`
+void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, int batch, hipStream_t s);
+// per (level, frame): border filter, retainBest(2*quota) by FAST score, Harris
+// response, retainBest(quota); survivors in raster order
+void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
+                       const uint32_t *cand_count, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n, hipStream_t s);
+// concatenate the levels, intensity-centroid angle, cv::KeyPoint records
+void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
+                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s);
+// rBRIEF-256 steered by each keypoint's angle, sampled on its level's blurred image
+void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
+                          const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s);
 
 // ---- launchers (each enqueues on `s`, no sync) ---------------------------
 
