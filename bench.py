@@ -46,10 +46,10 @@ def build_inputs(streams, frames, seed):
     return cam, np.concatenate([f] * streams), np.concatenate([d] * streams)
 
 
-def cpu_baseline(cam, frames, depth, n_frames, max_features):
+def cpu_baseline(cam, frames, depth, n_frames, max_features, orb_levels):
     """The oracle pipeline on one host core, over a bounded sample of the same workload."""
     from oracle.pipeline import OracleStream
-    ref = OracleStream((cam.fx, cam.fy, cam.cx, cam.cy), max_features, 20)
+    ref = OracleStream((cam.fx, cam.fy, cam.cx, cam.cy), max_features, 20, orb_levels=orb_levels)
     period = len(frames)
     ref.process(frames[0], depth[0])  # first frame: detect only, not timed
     t0 = time.perf_counter()
@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=2,
                     help="vo_ctx objects per GPU (each owns streams/contexts camera streams and one HIP "
                          "stream); batches of different contexts overlap on the GPU")
+    ap.add_argument("--detector", choices=("orb", "fast"), default="orb",
+                    help="orb: full ORB detector, 8-level pyramid; fast: FAST corners + ORB::compute on one "
+                         "level, the sequence the reference node executes")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames timed for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -101,10 +104,12 @@ def main():
     frames_d = [torch.from_numpy(frames_h).cuda() for _ in range(NC)]
     depth_d = [torch.from_numpy(depth_h).cuda() for _ in range(NC)]
     ctxs = []
+    levels = 8 if args.detector == "orb" else 0
+    cap = args.features + (64 if levels else 0)  # room for boundary ties of the per-level ranking
     for _ in range(NC):
-        c = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=args.features, max_batch=Bc)
+        c = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=Bc)
         c.batch_configure(W, H, C, n_streams=S, frames_per_stream=F, max_features=args.features,
-                          fast_threshold=20, camera=K)
+                          fast_threshold=20, camera=K, orb_levels=levels)
         ctxs.append(c)
     ctx = ctxs[0]
 
@@ -170,7 +175,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32 (image, match), f64 (RANSAC)", "data": "synthetic",
-            "config": {"workload": "hd720_bgra_mono_stream_2000kp_modeA_ratio_Fransac_pnp",
+            "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
+                                   ("orb8level" if levels else "fast1level"),
                        "streams_per_gpu": S * NC, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
                        "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,
@@ -183,7 +189,7 @@ def main():
             "pose_success_rate": float(res["pnp_success"].mean()),
         }
         if world == 1 and args.cpu_frames > 0:
-            cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features)
+            cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_frames} HD720 frames of the same stream, "
                                              "oracle C pipeline, 1 thread"}

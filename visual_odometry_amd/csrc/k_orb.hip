@@ -290,7 +290,12 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
 
 // -------------------------------------------------- orientation + keypoints
 
-__device__ const int kUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// half-width of the radius-15 disc at row |v| (ORB's umax table)
+__device__ __forceinline__ constexpr int kUmaxC(int v)
+{
+    constexpr int t[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    return t[v];
+}
 
 // cv::fastAtan2, scalar path (degrees)
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -346,16 +351,26 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
     const int y = ras / (uint32_t)L.w, x = ras - y * L.w;
     const uint8_t *center = pyr + (size_t)f * plan.frame_bytes + L.off + (size_t)y * L.pitch + x;
 
+    // Row v = -15 + half + 2k for k = 0..15 (v = 16 does not exist: masked).  All 16 loads
+    // are issued before the first use; the disc test only gates the accumulation.
     const int u = (lane & 31) - 15, half = lane >> 5;
+    const int au = abs(u);
     int m10 = 0, m01 = 0;
-    if (u <= 15) {
-        for (int v = -15 + half; v <= 15; v += 2) {
-            if (abs(u) <= kUmax[abs(v)]) {
-                const int val = center[v * L.pitch + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
-        }
+    int val[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int v = min(-15 + half + 2 * k, 15);
+        val[k] = center[v * L.pitch + min(u, 15)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int v0 = -15 + 2 * k, v1 = -14 + 2 * k;  // compile-time rows of the two half-waves
+        const int d0 = kUmaxC(v0 < 0 ? -v0 : v0), d1 = v1 > 15 ? -1 : kUmaxC(v1 < 0 ? -v1 : v1);
+        const int d = half ? d1 : d0;
+        const int v = half ? v1 : v0;
+        const int x = au <= d ? val[k] : 0;
+        m10 += u * x;
+        m01 += v * x;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
