@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Phase-by-phase cycle breakdown of the fused front-end kernel from the
+diagnostic build (make -C profiles/diag): median cycles between consecutive
+stamps of wave 0 over a window of 4096 blocks in the middle of a launch."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch  # first: the library must bind to the HIP runtime torch loads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from visual_odometry_amd import capi, synth  # noqa: E402
+
+capi.LIB_PATH = os.path.join(ROOT, "profiles", "diag", "libvo_hip_diag.so")
+lib = capi.load()
+
+cam = synth.CONFIG_CAMERAS["hd720"]
+seq = synth.make_sequence(cam, 2, seed=1, channels=4)
+S, F = 16, 16
+frames = torch.from_numpy(np.concatenate([seq["frames"]] * (S * F // 2))).cuda()
+depth = torch.from_numpy(np.concatenate([seq["depth"]] * (S * F // 2))).cuda()
+ctx = capi.Context(0, cam.width, cam.height, 2000, S * F)
+ctx.batch_configure(cam.width, cam.height, 4, S, F, max_features=2000,
+                    camera=(cam.fx, cam.fy, cam.cx, cam.cy))
+for _ in range(3):
+    ctx.batch_submit_ptr(frames.data_ptr(), cam.width * 4, cam.width * 4 * cam.height, depth.data_ptr(), cam.width,
+                         cam.width * cam.height)
+    ctx.batch_wait()
+out = np.zeros((4096, 16), np.uint64)
+raw = C.CDLL(capi.LIB_PATH)
+raw.vo_debug_fe_stamps.argtypes = [C.c_void_p]
+assert raw.vo_debug_fe_stamps(out.ctypes.data) == 0
+t = out[:, :10].astype(np.int64)
+d = np.diff(t, axis=1)
+names = ["issue loads", "wait loads + gray + LDS write", "barrier 1", "pre-test + wave queue", "score",
+         "blur row pass", "barrier 2", "NMS + emit", "blur column pass + outputs"]
+ok = (t[:, 9] > 0)
+print("blocks with stamps:", int(ok.sum()))
+for i, n in enumerate(names):
+    col = d[ok, i]
+    col = col[(col >= 0) & (col < 10 ** 7)]
+    print(f"{n:32s} median {np.median(col):8.0f}  p90 {np.percentile(col, 90):8.0f} cycles")
+tot = t[ok, 9] - t[ok, 0]
+print(f"{'start -> end':32s} median {np.median(tot):8.0f}  p90 {np.percentile(tot, 90):8.0f} cycles")

@@ -24,15 +24,6 @@ __device__ __forceinline__ uint32_t gray_of(uint32_t b, uint32_t g, uint32_t r, 
     return (b * c.b + g * c.g + r * c.r + (1u << (c.shift - 1))) >> c.shift;
 }
 
-// byte k (0..11) of the 96-bit little-endian window {d0, d1, d2}
-template <int K>
-__device__ __forceinline__ uint32_t win_byte(uint32_t d0, uint32_t d1, uint32_t d2)
-{
-    static_assert(K >= 0 && K < 12, "window is 12 bytes");
-    uint32_t d = K < 4 ? d0 : (K < 8 ? d1 : d2);
-    return __builtin_amdgcn_ubfe(d, 8 * (K & 3), 8);
-}
-
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
 __device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
 
@@ -92,8 +83,11 @@ constexpr int FE_SROWS = FE_TH + 2;    // score rows: image y0-1 .. y0+TH
 constexpr int FE_HROWS = FE_TH + 6;    // row-sum rows: image y0-3 .. y0+TH+2
 constexpr int FE_THREADS = 512;
 constexpr int FE_WAVES = FE_THREADS / 64;
-constexpr int FE_QCAP = (FE_TW + 2) * (FE_TH + 2);
-constexpr int FE_HALO_PIX = 2 * (FE_TW + 2) + 2 * FE_TH;
+constexpr int FE_HALO_PIX = 2 * (FE_TW + 2) + 2 * FE_TH;             // 1-px rim around the tile
+constexpr int FE_RIM_PER_WAVE = (FE_HALO_PIX + FE_WAVES - 1) / FE_WAVES;
+constexpr int FE_WQ = FE_TW * FE_TH / FE_WAVES + FE_RIM_PER_WAVE;     // queue entries one wave can produce
+static_assert(FE_TW == kTileW && FE_TH == kTileH, "candidate lists are indexed by this tile grid");
+static_assert(FE_THREADS == FE_TW / 4 * FE_TH && FE_RIM_PER_WAVE <= 64, "one quad per thread, rim fits a wave");
 
 // FAST-9/16 score of one pixel from its 16 ring values p[] and centre v:
 //   A = max over the 16 arcs of 9 of min(v - p) = v - min_arcs(max_arc p)
@@ -132,39 +126,72 @@ __device__ __forceinline__ bool fast_quick(uint32_t v, uint32_t p0, uint32_t p8,
     return b || d;
 }
 
-// 7-tap row sum of pixel i (window byte 4+i) from one 12-byte row window
-template <int I>
-__device__ __forceinline__ uint32_t hsum7(uint32_t d0, uint32_t d1, uint32_t d2)
+#ifdef VO_FE_STAMPS
+// Diagnostic build only: cycle stamps of wave 0 of a window of blocks.
+constexpr int FE_STAMP_N = 16, FE_STAMP_BLOCKS = 4096, FE_STAMP_FIRST = 40000;
+__device__ unsigned long long g_fe_stamps[FE_STAMP_BLOCKS * FE_STAMP_N];
+#define FE_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x >= FE_STAMP_FIRST && blockIdx.x < FE_STAMP_FIRST + FE_STAMP_BLOCKS) \
+            g_fe_stamps[(blockIdx.x - FE_STAMP_FIRST) * FE_STAMP_N + (i)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define FE_STAMP(i) do { } while (0)
+#endif
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
+
+// bytes A and B (0..3 from lo, 4..7 from hi) of the 8-byte pool {hi, lo}, zero-extended to two u16
+template <int A, int B>
+__device__ __forceinline__ us2 pair_of(uint32_t hi, uint32_t lo)
 {
-    return 18u * (win_byte<1 + I>(d0, d1, d2) + win_byte<7 + I>(d0, d1, d2)) +
-           34u * (win_byte<2 + I>(d0, d1, d2) + win_byte<6 + I>(d0, d1, d2)) +
-           49u * (win_byte<3 + I>(d0, d1, d2) + win_byte<5 + I>(d0, d1, d2)) +
-           55u * win_byte<4 + I>(d0, d1, d2);
+    return as_us2(__builtin_amdgcn_perm(hi, lo, (uint32_t)A | 0x0c00u | ((uint32_t)B << 16) | 0x0c000000u));
 }
 
+// fast_quick() for the two pixels at window bytes 4+I and 5+I of the middle
+// row, in packed 16-bit arithmetic.  d0..d2: the middle row's 12-byte window,
+// up1/dn1: the dword above/below d1 at distance 3.  With
+//   M = min(max(p0,p8), max(p4,p12)),  m = max(min(p0,p8), min(p4,p12))
+// the test "both pairs hold a pixel > v+t, or both a pixel < v-t" is
+// max(M - v, v - m) > t (saturating differences).  Returns per 16-bit half a
+// non-zero value when the pixel passes.
 template <int I>
-__device__ __forceinline__ bool quick_px(const uint32_t (&up)[3], const uint32_t (&mid)[3], const uint32_t (&dn)[3],
-                                         int thr)
+__device__ __forceinline__ uint32_t quick_pair(uint32_t up1, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t dn1,
+                                               us2 tt)
 {
-    return fast_quick(win_byte<4 + I>(mid[0], mid[1], mid[2]), win_byte<4 + I>(dn[0], dn[1], dn[2]),
-                      win_byte<4 + I>(up[0], up[1], up[2]), win_byte<7 + I>(mid[0], mid[1], mid[2]),
-                      win_byte<1 + I>(mid[0], mid[1], mid[2]), thr);
+    const us2 v = pair_of<I, I + 1>(0u, d1);
+    const us2 p0 = pair_of<I, I + 1>(0u, dn1);
+    const us2 p8 = pair_of<I, I + 1>(0u, up1);
+    const us2 p4 = pair_of<3 + I, 4 + I>(d2, d1);
+    const us2 p12 = pair_of<1 + I, 2 + I>(d1, d0);
+    const us2 M = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
+    const us2 m = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+    const us2 e = __builtin_elementwise_max(__builtin_elementwise_sub_sat(M, v), __builtin_elementwise_sub_sat(v, m));
+    return as_u32(__builtin_elementwise_sub_sat(e, tt));
 }
 
-// strict 3x3 maximum test of window byte 4+I of the middle row
-template <int I>
-__device__ __forceinline__ bool nms_px(const uint32_t (&a)[3], const uint32_t (&m)[3], const uint32_t (&b)[3])
+// 7-tap row sums [18,34,49,55,49,34,18] of the four pixels at window bytes
+// 4..7, two 4-byte dot products each, packed as two u16 pairs
+__device__ __forceinline__ void hsum7_quad(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t (&h)[4])
 {
-    const uint32_t s = win_byte<4 + I>(m[0], m[1], m[2]);
-    if (!s) return false;
-    return s > win_byte<3 + I>(a[0], a[1], a[2]) && s > win_byte<4 + I>(a[0], a[1], a[2]) &&
-           s > win_byte<5 + I>(a[0], a[1], a[2]) && s > win_byte<3 + I>(m[0], m[1], m[2]) &&
-           s > win_byte<5 + I>(m[0], m[1], m[2]) && s > win_byte<3 + I>(b[0], b[1], b[2]) &&
-           s > win_byte<4 + I>(b[0], b[1], b[2]) && s > win_byte<5 + I>(b[0], b[1], b[2]);
+    constexpr uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps 0..3
+    constexpr uint32_t WB = 49u | (34u << 8) | (18u << 16);               // taps 4..6
+    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), WA,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), WB, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), WA,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), WB, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), WA,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), WB, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(d1, WA, __builtin_amdgcn_udot4(d2, WB, 0u, false), false);
 }
 
 constexpr int FE_TASKS = FE_GROWS * (FE_PITCH / 4);  // 4-pixel staging tasks per tile
 constexpr int FE_TPT = (FE_TASKS + FE_THREADS - 1) / FE_THREADS;  // tasks per thread
+constexpr int FE_HPAIRS = FE_HROWS / 2;              // row pairs of row sums
+static_assert(kTileCap == FE_TW * FE_TH / 4, "a tile emits at most one corner per 2x2 block");
+static_assert(FE_HROWS % 2 == 0 && FE_TH % 2 == 0, "rows are processed in pairs");
 
 // Pixels of one staging task (4 horizontally adjacent pixels), still in the
 // layout they were loaded in.
@@ -177,6 +204,29 @@ struct FeTile {
     int frame, x0, y0;
     bool inside;  // the tile and its apron lie inside the image: no reflection
 };
+
+// gray weights split into byte planes for 4-byte dot products:
+// gray = (dot4(px, lo) + (dot4(px, hi) << 8) + round) >> shift
+struct GrayDot {
+    uint32_t lo, hi, round;
+    int shift;
+};
+__device__ __forceinline__ GrayDot gray_dot(GrayCoeffs c)
+{
+    GrayDot g;
+    g.lo = ((uint32_t)c.b & 255u) | (((uint32_t)c.g & 255u) << 8) | (((uint32_t)c.r & 255u) << 16);
+    g.hi = (((uint32_t)c.b >> 8) & 255u) | ((((uint32_t)c.g >> 8) & 255u) << 8) | ((((uint32_t)c.r >> 8) & 255u) << 16);
+    g.round = 1u << (c.shift - 1);
+    g.shift = c.shift;
+    return g;
+}
+// px holds B, G, R in its three low bytes (the fourth byte is ignored)
+__device__ __forceinline__ uint32_t gray_dot_px(uint32_t px, GrayDot g)
+{
+    const uint32_t lo = __builtin_amdgcn_udot4(px, g.lo, g.round, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(px, g.hi, 0u, false);
+    return (lo + (hi << 8)) >> g.shift;
+}
 
 // issue the global loads of staging task i of a tile (no wait)
 template <int CN>
@@ -210,26 +260,24 @@ __device__ __forceinline__ void fe_issue(FePre<CN> &p, const uint8_t *img, int s
 
 // four gray bytes of a loaded task
 template <int CN>
-__device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, GrayCoeffs c)
+__device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, GrayDot g)
 {
     uint32_t out = 0;
     if (CN == 4) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            out |= gray_of(p.v[j] & 255u, (p.v[j] >> 8) & 255u, (p.v[j] >> 16) & 255u, c) << (8 * j);
+        for (int j = 0; j < 4; j++) out |= gray_dot_px(p.v[j], g) << (8 * j);
     } else if (CN == 1) {
         if (packed) out = p.v[0];
         else out = p.v[0] | (p.v[1] << 8) | (p.v[2] << 16) | (p.v[3] << 24);
     } else if (packed) {
-        // 12 bytes B0 G0 R0 B1 ... R3 in three dwords
+        // 12 bytes B0 G0 R0 B1 ... R3 in three dwords: pixel j starts at byte 3j
         const uint32_t d0 = p.v[0], d1 = p.v[1], d2 = p.v[2];
-        out = gray_of(d0 & 255u, (d0 >> 8) & 255u, (d0 >> 16) & 255u, c) |
-              (gray_of(d0 >> 24, d1 & 255u, (d1 >> 8) & 255u, c) << 8) |
-              (gray_of((d1 >> 16) & 255u, d1 >> 24, d2 & 255u, c) << 16) |
-              (gray_of((d2 >> 8) & 255u, (d2 >> 16) & 255u, d2 >> 24, c) << 24);
+        out = gray_dot_px(d0, g) | (gray_dot_px(__builtin_amdgcn_alignbyte(d1, d0, 3), g) << 8) |
+              (gray_dot_px(__builtin_amdgcn_alignbyte(d2, d1, 2), g) << 16) | (gray_dot_px(d2 >> 8, g) << 24);
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) out |= gray_of(p.v[3 * j], p.v[3 * j + 1], p.v[3 * j + 2], c) << (8 * j);
+        for (int j = 0; j < 4; j++)
+            out |= gray_dot_px(p.v[3 * j] | (p.v[3 * j + 1] << 8) | (p.v[3 * j + 2] << 16), g) << (8 * j);
     }
     return out;
 }
@@ -237,13 +285,18 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
 // One block = one 128x16 tile of one frame:
 //   0. the tile plus a 4-px apron is staged in LDS as 8-bit gray (BGR/BGRA are
 //      converted on the way in; 16-B vector loads, all issued before first use);
-//   1. cheap FAST pre-test on the tile and its 1-px rim; survivors are queued
-//      in LDS (wave ballot + one LDS atomic per wave);
-//   2. the queue is processed densely: full FAST-9/16 score into an LDS score tile;
-//   3. 3x3 strict non-max suppression on the tile (cv::FAST, nonmaxSuppression
-//      = true), survivors appended to the frame's candidate list as keys
-//      ((255-score) << 24) | raster index, one global atomic per block and tile;
-//   4. 7x7 Gaussian through 16-bit row sums.
+//   1. per wave, without block-level synchronisation: cheap FAST pre-test of
+//      the wave's two tile rows and its share of the 1-px rim in packed 16-bit
+//      arithmetic, survivors compacted into the wave's own LDS queue (ballot +
+//      lane prefix), full FAST-9/16 score of the queued pixels into the LDS
+//      score tile.  The Gaussian's row sums (4-byte dot products, two rows per
+//      task) are computed in the same barrier interval;
+//   2. 3x3 strict non-max suppression (cv::FAST, nonmaxSuppression = true) of
+//      the wave's queued corners; survivors go straight to the tile's slot list
+//      in global memory as keys ((255-score) << 24) | raster index (slots from
+//      an LDS counter; the wave that finishes last stores the tile's count --
+//      no global atomics, no zero-initialised counters).  The Gaussian's column
+//      pass (2-element dot products over row pairs) runs in the same interval.
 // tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
 //
 // Tile order is XCD-aware: blocks b and b+8 share an XCD (and its L2), so XCD
@@ -256,15 +309,13 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          size_t src_frame_stride, PlaneBatch gray_out,
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
-                                                         uint32_t *__restrict__ cand_count, int cand_cap,
-                                                         int batch)
+                                                         uint32_t *__restrict__ tile_count, int batch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t s_hsum[FE_HROWS * FE_TW];
-    __shared__ uint16_t s_queue[FE_QCAP];
-    __shared__ uint32_t s_qcount, s_base;
-    __shared__ uint32_t s_wave[FE_WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hpair[FE_HPAIRS * FE_TW];  // row sums of rows (2p, 2p+1)
+    __shared__ uint16_t s_queue[FE_WAVES * FE_WQ];
+    __shared__ uint32_t s_ecount, s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
@@ -276,69 +327,78 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     const bool aligned = CN == 4 ? ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 15) == 0)
                                  : ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 3) == 0);
 
-    auto decode = [&](int k) {
-        FeTile t;
-        const int col = (k / tiles_y) * 8 + xcd, ty = k - (k / tiles_y) * tiles_y;
-        t.frame = col / tiles_x;
-        t.x0 = (col - t.frame * tiles_x) * FE_TW;
-        t.y0 = ty * FE_TH;
-        t.inside = t.x0 >= 4 && t.x0 + FE_PITCH - 4 <= width && t.y0 >= 4 && t.y0 + FE_GROWS - 4 <= height;
-        return t;
-    };
-
-    const int k = j0;
-    if (k >= count) return;
-    const FeTile tile = decode(k);
+    if (j0 >= count) return;
+    FeTile tile;
+    {
+        const int col = (j0 / tiles_y) * 8 + xcd, ty = j0 - (j0 / tiles_y) * tiles_y;
+        tile.frame = col / tiles_x;
+        tile.x0 = (col - tile.frame * tiles_x) * FE_TW;
+        tile.y0 = ty * FE_TH;
+        tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
+                      tile.y0 + FE_GROWS - 4 <= height;
+    }
     const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
 
+    FE_STAMP(0);
     // ---- 0. stage: all global loads of the thread are issued before the first use
     {
         FePre<CN> pre[FE_TPT];
         const uint8_t *img = src + f * src_frame_stride;
+        const GrayDot gd = gray_dot(c);
 #pragma unroll
         for (int u = 0; u < FE_TPT; u++)
             if (tid + u * FE_THREADS < FE_TASKS)
                 fe_issue<CN>(pre[u], img, src_stride, width, height, tile, tid + u * FE_THREADS, aligned);
         for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
-        if (tid == 0) s_qcount = 0;
+        if (tid == 0) { s_ecount = 0; s_done = 0; }
+        FE_STAMP(1);
 #pragma unroll
         for (int u = 0; u < FE_TPT; u++) {
             const int i = tid + u * FE_THREADS;
             if (i < FE_TASKS) {
                 const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
                 *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) =
-                    fe_gray4<CN>(pre[u], tile.inside && aligned, c);
+                    fe_gray4<CN>(pre[u], tile.inside && aligned, gd);
             }
         }
     }
+    FE_STAMP(2);
     __syncthreads();
+    FE_STAMP(3);
 
     const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
     const int x = x0 + gx * 4, y = y0 + gy;  // image position of the first of them
     const bool want_fast = score.base != nullptr || cand != nullptr;
+    int qn = 0;  // entries in this wave's queue
 
     if (want_fast) {
         // ---- 1. pre-test: interior (four pixels per thread) ...
-        uint32_t pass = 0;
+        // bit i of vm: pixel x+i lies where cv::FAST evaluates (3 px inside the image)
+        uint32_t vm = 0;
         if (y >= 3 && y < height - 3) {
-            uint32_t up[3], mid[3], dn[3];
-            const uint32_t *ru = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 1) * FE_PITCH + gx * 4]);
-            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4]);
-            const uint32_t *rd = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 7) * FE_PITCH + gx * 4]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { up[k] = ru[k]; mid[k] = rm[k]; dn[k] = rd[k]; }
-            pass = (quick_px<0>(up, mid, dn, thr) && x + 0 >= 3 && x + 0 < width - 3 ? 1u : 0u) |
-                   (quick_px<1>(up, mid, dn, thr) && x + 1 >= 3 && x + 1 < width - 3 ? 2u : 0u) |
-                   (quick_px<2>(up, mid, dn, thr) && x + 2 >= 3 && x + 2 < width - 3 ? 4u : 0u) |
-                   (quick_px<3>(up, mid, dn, thr) && x + 3 >= 3 && x + 3 < width - 3 ? 8u : 0u);
+            const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
+            if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         }
-        // ... and the 1-px rim around the tile (one pixel per thread)
+        uint32_t r01 = 0, r23 = 0;
+        if (vm) {
+            const uint32_t up1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 1) * FE_PITCH + gx * 4 + 4]);
+            const uint32_t dn1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 7) * FE_PITCH + gx * 4 + 4]);
+            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4]);
+            const uint32_t d0 = rm[0], d1 = rm[1], d2 = rm[2];
+            const us2 tt = as_us2((uint32_t)thr * 0x00010001u);
+            r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
+            r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
+        }
+        const bool pass0 = (r01 & 0xffffu) != 0 && (vm & 1u), pass1 = (r01 >> 16) != 0 && (vm & 2u);
+        const bool pass2 = (r23 & 0xffffu) != 0 && (vm & 4u), pass3 = (r23 >> 16) != 0 && (vm & 8u);
+        // ... and this wave's share of the 1-px rim around the tile (one pixel per lane)
         int hr = -1, hc = 0;
-        if (tid < FE_HALO_PIX) {
-            if (tid < FE_TW + 2) { hr = 3; hc = 3 + tid; }
-            else if (tid < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + tid - (FE_TW + 2); }
-            else if (tid < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + tid - 2 * (FE_TW + 2); hc = 3; }
-            else { hr = 4 + tid - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
+        const int rim = wave * FE_RIM_PER_WAVE + lane;
+        if (lane < FE_RIM_PER_WAVE && rim < FE_HALO_PIX) {
+            if (rim < FE_TW + 2) { hr = 3; hc = 3 + rim; }
+            else if (rim < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + rim - (FE_TW + 2); }
+            else if (rim < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + rim - 2 * (FE_TW + 2); hc = 3; }
+            else { hr = 4 + rim - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
             const int ix = x0 - 4 + hc, iy = y0 - 4 + hr;
             bool ok = ix >= 3 && ix < width - 3 && iy >= 3 && iy < height - 3;
             if (ok) {
@@ -347,34 +407,29 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             }
             if (!ok) hr = -1;
         }
-        // queue the survivors: one LDS atomic per wave
+        // compact the survivors into this wave's queue
+        uint16_t *wq = s_queue + wave * FE_WQ;
         {
             uint64_t m[5];
-            uint32_t total = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { m[i] = __ballot((pass >> i) & 1u); total += (uint32_t)__popcll(m[i]); }
+            m[0] = __ballot(pass0); m[1] = __ballot(pass1); m[2] = __ballot(pass2); m[3] = __ballot(pass3);
             m[4] = __ballot(hr >= 0);
-            total += (uint32_t)__popcll(m[4]);
+            const uint64_t lt = (1ull << lane) - 1ull;
+            const bool pass[4] = {pass0, pass1, pass2, pass3};
             uint32_t base = 0;
-            if (total) {
-                if (lane == 0) base = atomicAdd(&s_qcount, total);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if ((pass >> i) & 1u)
-                        s_queue[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
-                    base += (uint32_t)__popcll(m[i]);
-                }
-                if (hr >= 0) s_queue[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
+            for (int i = 0; i < 4; i++) {
+                if (pass[i]) wq[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
+                base += (uint32_t)__popcll(m[i]);
             }
+            if (hr >= 0) wq[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
+            qn = (int)(base + (uint32_t)__popcll(m[4]));
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        FE_STAMP(4);
 
-        // ---- 2. full score of the queued pixels
-        const int qn = (int)s_qcount;
-        for (int e = tid; e < qn; e += FE_THREADS) {
-            const int q = s_queue[e];
+        // full score of the wave's queued pixels
+        for (int e = lane; e < qn; e += 64) {
+            const int q = wq[e];
             const int r = q >> 8, cc = q & 255;
             const uint8_t *p = &s_gray[r * FE_PITCH + cc];
             uint32_t ring[16];
@@ -386,94 +441,119 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             ring[15] = p[3 * FE_PITCH - 1];
             s_score[(r - 3) * FE_PITCH + cc] = (uint8_t)fast_score(ring, p[0], thr);
         }
-        __syncthreads();
+    }
 
-        // ---- 3. non-max suppression + emission (score row sr <-> tile row sr + 3)
-        uint32_t sa[3], sm[3], sb[3];
-        {
-            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_score[(gy + 0) * FE_PITCH + gx * 4]);
-            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_score[(gy + 1) * FE_PITCH + gx * 4]);
-            const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_score[(gy + 2) * FE_PITCH + gx * 4]);
-#pragma unroll
-            for (int k = 0; k < 3; k++) { sa[k] = ra[k]; sm[k] = rm[k]; sb[k] = rb[k]; }
+    FE_STAMP(5);
+    // ---- Gaussian, row pass: row sums of tile rows 1 .. 22, two rows per task
+    if (blur.base) {
+        for (int t = tid; t < FE_HPAIRS * 32; t += FE_THREADS) {
+            const int hp = t >> 5, tg = t & 31;
+            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 1) * FE_PITCH + tg * 4]);
+            const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 2) * FE_PITCH + tg * 4]);
+            uint32_t ha[4], hb[4];
+            hsum7_quad(ra[0], ra[1], ra[2], ha);
+            hsum7_quad(rb[0], rb[1], rb[2], hb);
+            uint4 o;
+            o.x = ha[0] | (hb[0] << 16); o.y = ha[1] | (hb[1] << 16);
+            o.z = ha[2] | (hb[2] << 16); o.w = ha[3] | (hb[3] << 16);
+            *reinterpret_cast<uint4 *>(&s_hpair[hp * FE_TW + tg * 4]) = o;
         }
-        if (score.base)  // planes are padded to whole tiles: always in bounds
-            *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) = sm[1];
-        if (cand) {
-            uint32_t flags = 0;
-            if (sm[1]) {
-                flags = (nms_px<0>(sa, sm, sb) ? 1u : 0u) | (nms_px<1>(sa, sm, sb) ? 2u : 0u) |
-                        (nms_px<2>(sa, sm, sb) ? 4u : 0u) | (nms_px<3>(sa, sm, sb) ? 8u : 0u);
-            }
-            uint64_t m[4];
-            uint32_t total = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { m[i] = __ballot((flags >> i) & 1u); total += (uint32_t)__popcll(m[i]); }
-            if (lane == 0) s_wave[wave] = total;
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t tot = 0;
-#pragma unroll
-                for (int w = 0; w < FE_WAVES; w++) tot += s_wave[w];
-                s_base = tot ? atomicAdd(&cand_count[f], tot) : 0u;
-            }
-            __syncthreads();
-            if (total) {
-                uint32_t off = s_base;
-                for (int w = 0; w < wave; w++) off += s_wave[w];
-                const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if ((flags >> i) & 1u) {
-                        const uint32_t slot = off + __popcll(m[i] & lt);
-                        const uint32_t sc = (sm[1] >> (8 * i)) & 255u;
-                        if (slot < (uint32_t)cand_cap)
-                            cand[(size_t)f * cand_cap + slot] = ((255u - sc) << 24) | (uint32_t)(y * width + x + i);
-                    }
-                    off += (uint32_t)__popcll(m[i]);
+    }
+    FE_STAMP(6);
+    __syncthreads();
+    FE_STAMP(7);
+
+    // ---- 2. non-max suppression of this wave's corners (score row sr <-> tile row sr + 3), direct emission
+    if (cand) {
+        const int tile_id = (y0 / FE_TH) * tiles_x + x0 / FE_TW;
+        uint32_t *out = cand + ((size_t)f * tiles_x * tiles_y + tile_id) * kTileCap;
+        const uint16_t *wq = s_queue + wave * FE_WQ;
+        for (int e0 = 0; e0 < qn; e0 += 64) {
+            const int e = e0 + lane;
+            bool is_max = false;
+            uint32_t key = 0;
+            if (e < qn) {
+                const int q = wq[e];
+                const int r = q >> 8, cc = q & 255;
+                // rim pixels only feed their neighbours
+                if (r >= 4 && r < 4 + FE_TH && cc >= 4 && cc < 4 + FE_TW) {
+                    const uint8_t *sp = &s_score[(r - 3) * FE_PITCH + cc];
+                    const uint32_t sc = sp[0];
+                    is_max = sc && sc > sp[-FE_PITCH - 1] && sc > sp[-FE_PITCH] && sc > sp[-FE_PITCH + 1] &&
+                             sc > sp[-1] && sc > sp[1] && sc > sp[FE_PITCH - 1] && sc > sp[FE_PITCH] &&
+                             sc > sp[FE_PITCH + 1];
+                    key = ((255u - sc) << 24) | (uint32_t)((y0 - 4 + r) * width + (x0 - 4 + cc));
                 }
             }
+            const uint64_t mm = __ballot(is_max);
+            if (mm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_ecount, (uint32_t)__popcll(mm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (is_max) out[base + __popcll(mm & ((1ull << lane) - 1ull))] = key;
+            }
         }
+        // the wave that arrives last publishes the tile's corner count
+        if (lane == 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slot reservations are done
+            if (atomicAdd(&s_done, 1u) == FE_WAVES - 1)
+                tile_count[(size_t)f * tiles_x * tiles_y + tile_id] = s_ecount;
+        }
+    }
+    FE_STAMP(8);
+
+    // ---- Gaussian, column pass: output rows (2m, 2m+1) from the row pairs m .. m+3
+    if (blur.base && tid < (FE_TH / 2) * 32) {
+        const int m = tid >> 5, tg = tid & 31;
+        uint4 P[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4 *>(&s_hpair[(m + k) * FE_TW + tg * 4]);
+        // even row: taps (18,34)(49,55)(49,34)(18,-); odd row: (-,18)(34,49)(55,49)(34,18)
+        constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
+        constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
+        uint32_t oe = 0, oo = 0;
+        const uint32_t col[4][4] = {{P[0].x, P[1].x, P[2].x, P[3].x}, {P[0].y, P[1].y, P[2].y, P[3].y},
+                                    {P[0].z, P[1].z, P[2].z, P[3].z}, {P[0].w, P[1].w, P[2].w, P[3].w}};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t ae = 1u << 15, ao = 1u << 15;
+            ae = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(E0), ae, false);
+            ae = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(E1), ae, false);
+            ae = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(E2), ae, false);
+            ae = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(E3), ae, false);
+            ao = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(O0), ao, false);
+            ao = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(O1), ao, false);
+            ao = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(O2), ao, false);
+            ao = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(O3), ao, false);
+            oe |= min(ae >> 16, 255u) << (8 * i);
+            oo |= min(ao >> 16, 255u) << (8 * i);
+        }
+        const int yy = y0 + 2 * m, xx = x0 + tg * 4;
+        uint8_t *bp = blur.base + f * blur.plane_stride + (size_t)yy * blur.pitch + xx;
+        if (yy < height) *reinterpret_cast<uint32_t *>(bp) = oe;
+        if (yy + 1 < height) *reinterpret_cast<uint32_t *>(bp + blur.pitch) = oo;
     }
 
     if (gray_out.base && y < height)
         *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
             *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4 + 4]);
 
-    // ---- 4. Gaussian: row sums of tile rows 1 .. 22, then the column pass
-    if (blur.base) {
-        for (int t = tid; t < FE_HROWS * 32; t += FE_THREADS) {
-            const int hr = t >> 5, tg = t & 31;
-            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&s_gray[(hr + 1) * FE_PITCH + tg * 4]);
-            const uint32_t d0 = rw[0], d1 = rw[1], d2 = rw[2];
-            uint2 o;
-            o.x = hsum7<0>(d0, d1, d2) | (hsum7<1>(d0, d1, d2) << 16);
-            o.y = hsum7<2>(d0, d1, d2) | (hsum7<3>(d0, d1, d2) << 16);
-            *reinterpret_cast<uint2 *>(&s_hsum[hr * FE_TW + tg * 4]) = o;
-        }
-        __syncthreads();
-        uint32_t acc[4] = {0, 0, 0, 0};
-        const uint32_t kq[7] = {18, 34, 49, 55, 49, 34, 18};
-#pragma unroll
-        for (int r = 0; r < 7; r++) {
-            const uint2 h = *reinterpret_cast<const uint2 *>(&s_hsum[(gy + r) * FE_TW + gx * 4]);
-            acc[0] += kq[r] * (h.x & 0xffffu);
-            acc[1] += kq[r] * (h.x >> 16);
-            acc[2] += kq[r] * (h.y & 0xffffu);
-            acc[3] += kq[r] * (h.y >> 16);
-        }
-        uint32_t o = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) o |= min((acc[i] + (1u << 15)) >> 16, 255u) << (8 * i);
-        if (y < height)
-            *reinterpret_cast<uint32_t *>(blur.base + f * blur.plane_stride + (size_t)y * blur.pitch + x) = o;
-    }
+    if (score.base)  // diagnostic score map; planes are padded to whole tiles: always in bounds
+        *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) =
+            *reinterpret_cast<const uint32_t *>(&s_score[(gy + 1) * FE_PITCH + gx * 4 + 4]);
+    FE_STAMP(9);
 }
+
+#ifdef VO_FE_STAMPS
+extern "C" int vo_debug_fe_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fe_stamps), sizeof(unsigned long long) * FE_STAMP_BLOCKS * FE_STAMP_N);
+}
+#endif
 
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
                      int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
-                     uint32_t *cand, uint32_t *cand_count, int cand_cap, int batch, GrayCoeffs c,
-                     hipStream_t s)
+                     uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s)
 {
     // block b serves XCD group b % 8, which owns the tile columns congruent to
     // b % 8; the grid holds the largest group's tile count for every group
@@ -483,13 +563,13 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, cand_count, cand_cap, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
 }
 
 // ---------------------------------------------------------------- select
@@ -521,7 +601,8 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *keys, int n_pow2)
 // Then KeyPointsFilter::runByImageBorder(31) as done inside ORB::compute
 // (reference src/feature_detector.cpp:73), order preserved.
 __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restrict__ cand,
-                                                        const uint32_t *__restrict__ cand_count, int cand_cap,
+                                                        const uint32_t *__restrict__ tile_count,
+                                                        uint32_t *__restrict__ flat, int ntiles,
                                                         int width, int height, int max_features, int border,
                                                         vo_kp *__restrict__ kps, int kp_stride,
                                                         int *__restrict__ nkp)
@@ -534,8 +615,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
-    const uint32_t *c = cand + (size_t)f * cand_cap;
-    const int M = min((int)cand_count[f], cand_cap);
+    // the frame's corners as one list (s_keys and s_scan are free until the gather below)
+    uint32_t *c = flat + (size_t)f * ntiles * kTileCap;
+    const int M = flatten_tile_lists<SEL_THREADS>(cand + (size_t)f * ntiles * kTileCap,
+                                                  tile_count + (size_t)f * ntiles, ntiles, c, s_keys, s_scan);
     const bool all = M <= max_features;
 
     if (tid == 0) { s_count = 0; s_cut_bin = 256; s_need = 0; s_cut_row = kMaxDim; }
@@ -638,12 +721,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
     if (tid == SEL_THREADS - 1) nkp[f] = (int)s_scan[tid];
 }
 
-void launch_select(const uint32_t *cand, const uint32_t *cand_count, int cand_cap, int width, int height,
+void launch_select(const uint32_t *cand, const uint32_t *tile_count, uint32_t *flat, int width, int height,
                    int max_features, int border, vo_kp *kps, int kp_stride, int *nkp, int batch,
                    hipStream_t s)
 {
-    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_THREADS), 0, s, cand, cand_count, cand_cap, width,
-                       height, max_features, border, kps, kp_stride, nkp);
+    hipLaunchKernelGGL(k_select, dim3(batch), dim3(SEL_THREADS), 0, s, cand, tile_count, flat,
+                       tiles_of(width, height), width, height, max_features, border, kps, kp_stride, nkp);
 }
 
 // ----------------------------------------------------------------- BRIEF

@@ -157,12 +157,14 @@ __device__ __forceinline__ float key_to_float(uint32_t k)
 // nth_element order (unspecified); here they are written in raster order.
 __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, const uint8_t *__restrict__ pyr,
                                                           const uint32_t *__restrict__ cand,
-                                                          const uint32_t *__restrict__ cand_count,
+                                                          const uint32_t *__restrict__ tile_count,
+                                                          uint32_t *__restrict__ flat,
                                                           uint32_t *__restrict__ lvl_ras,
                                                           float *__restrict__ lvl_resp, int *__restrict__ lvl_n)
 {
-    __shared__ uint32_t s_ras[OS_K1CAP];
-    __shared__ uint32_t s_key[OS_K1CAP];
+    __shared__ uint32_t s_buf[2 * OS_K1CAP];
+    __shared__ uint32_t s_scan[OS_THREADS];
+    uint32_t *const s_ras = s_buf, *const s_key = s_buf + OS_K1CAP;
     __shared__ uint32_t s_oras[kOrbLevelCap];
     __shared__ uint32_t s_okey[kOrbLevelCap];
     __shared__ uint32_t s_hist[256];
@@ -172,8 +174,11 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
-    const uint32_t *c = cand + L.cand_off + (size_t)f * L.cand_cap;
-    const int M = min((int)cand_count[l * batch + f], L.cand_cap);
+    // the level's corners as one list (s_buf is free until the gather below)
+    uint32_t *c = flat + L.cand_off + (size_t)f * L.tiles * kTileCap;
+    const int M = flatten_tile_lists<OS_THREADS>(cand + L.cand_off + (size_t)f * L.tiles * kTileCap,
+                                                 tile_count + L.count_off + (size_t)f * L.tiles, L.tiles, c, s_buf,
+                                                 s_scan);
     const uint8_t *img = pyr + (size_t)f * plan.frame_bytes + L.off;
     const bool size_ok = w > 2 * border && h > 2 * border && quota > 0;
 
@@ -445,7 +450,7 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
     const float factor = (float)(1.0 / scale_factor);
     float per = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
     int sum = 0;
-    size_t off = 0, coff = 0;
+    size_t off = 0, coff = 0, noff = 0;
     for (int l = 0; l < nlevels; l++) {
         OrbLevel &L = p.lv[l];
         L.scale = (float)pow((double)scale_factor, (double)l);
@@ -463,9 +468,12 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
             L.quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
         }
         if (L.quota > kOrbLevelCap - 256 || 2 * L.quota + 512 > OS_K1CAP) return false;
-        L.cand_cap = L.w * L.h / 4 + 64;
+        L.tiles = tiles_of(L.w, L.h);
+        if (L.tiles > 2 * OS_K1CAP) return false;
         L.cand_off = coff;
-        coff += (size_t)L.cand_cap * batch;
+        coff += (size_t)L.tiles * kTileCap * batch;
+        L.count_off = noff;
+        noff += (size_t)L.tiles * batch;
         if (l > 0) {
             // the resize kernel's LDS footprint of one 128x16 output tile
             const OrbLevel &S = p.lv[l - 1];
@@ -475,6 +483,7 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
     }
     p.frame_bytes = off;
     p.cand_total = coff;
+    p.count_total = noff;
     *out = p;
     return true;
 }
@@ -486,10 +495,11 @@ void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
 }
 
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
-                       const uint32_t *cand_count, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n, hipStream_t s)
+                       const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
+                       hipStream_t s)
 {
     hipLaunchKernelGGL(k_orb_select, dim3(plan.nlevels, batch), dim3(OS_THREADS), 0, s, plan, batch, pyr, cand,
-                       cand_count, lvl_ras, lvl_resp, lvl_n);
+                       tile_count, flat, lvl_ras, lvl_resp, lvl_n);
 }
 
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,

@@ -122,15 +122,16 @@ int vo_ctx::allocate()
     plane_bytes = (size_t)pitch * hpad;
     kp_stride = align_up(cfg.max_features, 8);
     slots = 2 * B + 3;  // S*(F+1) <= 2B batch slots, two for the single-frame operators, one empty
-    cand_cap = cfg.max_width * cfg.max_height / 4 + 64;
+    max_tiles = tiles_of(cfg.max_width, cfg.max_height);
     in_frame_bytes = (size_t)cfg.max_width * cfg.max_height * 4;
 
     HIP_TRY(ctx, hipMalloc(&d_in, in_frame_bytes * B));
     HIP_TRY(ctx, hipMalloc(&d_gray, plane_bytes * B));
     HIP_TRY(ctx, hipMalloc(&d_score, plane_bytes * B));
     HIP_TRY(ctx, hipMalloc(&d_blur, plane_bytes * B));
-    HIP_TRY(ctx, hipMalloc(&d_cand, sizeof(uint32_t) * (size_t)cand_cap * B));
-    HIP_TRY(ctx, hipMalloc(&d_cand_count, sizeof(uint32_t) * B));
+    HIP_TRY(ctx, hipMalloc(&d_cand, sizeof(uint32_t) * (size_t)max_tiles * kTileCap * B));
+    HIP_TRY(ctx, hipMalloc(&d_cand_flat, sizeof(uint32_t) * (size_t)max_tiles * kTileCap * B));
+    HIP_TRY(ctx, hipMalloc(&d_cand_count, sizeof(uint32_t) * (size_t)max_tiles * B));
     HIP_TRY(ctx, hipMalloc(&d_kps, sizeof(vo_kp) * (size_t)kp_stride * slots));
     HIP_TRY(ctx, hipMalloc(&d_desc, (size_t)32 * kp_stride * slots));
     HIP_TRY(ctx, hipMalloc(&d_nkp, sizeof(int) * slots));
@@ -187,7 +188,7 @@ int vo_ctx::allocate()
 
 void vo_ctx::release()
 {
-    void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_count, d_kps, d_desc, d_nkp, d_pattern,
+    void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_flat, d_cand_count, d_orb_cand_flat, d_kps, d_desc, d_nkp, d_pattern,
                     d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0,
                     d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
@@ -249,7 +250,7 @@ int vo_fast_score(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int 
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = stage_image(c, gray, w, h, stride))) return rc;
     launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, c->plane(c->d_score),
-                    PlaneBatch{nullptr, 0, 0}, threshold, nullptr, nullptr, 0, 1, c->gc, c->stream);
+                    PlaneBatch{nullptr, 0, 0}, threshold, nullptr, nullptr, 1, c->gc, c->stream);
     HIP_TRY(c, hipMemcpy2DAsync(score, score_stride, c->d_score, c->pitch, w, h, hipMemcpyDefault, c->stream));
     return finish(c, "vo_fast_score");
 }
@@ -262,7 +263,7 @@ int vo_blur7(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, uint8_t *
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = stage_image(c, gray, w, h, stride))) return rc;
     launch_frontend(c->d_in, w, h, w, 0, 1, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
-                    c->plane(c->d_blur), 0, nullptr, nullptr, 0, 1, c->gc, c->stream);
+                    c->plane(c->d_blur), 0, nullptr, nullptr, 1, c->gc, c->stream);
     HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->d_blur, c->pitch, w, h, hipMemcpyDefault, c->stream));
     return finish(c, "vo_blur7");
 }
@@ -528,13 +529,12 @@ int vo_match_features_ex(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_d
 void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
                             int channels, int max_features, int fast_threshold, int batch, int first_slot)
 {
-    (void)hipMemsetAsync(d_cand_count, 0, sizeof(uint32_t) * batch, stream);
     mark(0);
     launch_frontend(src, w, h, src_stride, src_frame_stride, channels, PlaneBatch{nullptr, 0, 0},
-                    PlaneBatch{nullptr, 0, 0}, plane(d_blur), fast_threshold, d_cand, d_cand_count, cand_cap, batch,
-                    gc, stream);
+                    PlaneBatch{nullptr, 0, 0}, plane(d_blur), fast_threshold, d_cand, d_cand_count, batch, gc,
+                    stream);
     mark(1);
-    launch_select(d_cand, d_cand_count, cand_cap, w, h, max_features, kFBorder,
+    launch_select(d_cand, d_cand_count, d_cand_flat, w, h, max_features, kFBorder,
                   d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot, batch, stream);
     mark(2);
     launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
@@ -566,18 +566,26 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
     }
     if (p.cand_total > orb_cand_cap) {
         if (d_orb_cand) (void)hipFree(d_orb_cand);
-        d_orb_cand = nullptr;
+        if (d_orb_cand_flat) (void)hipFree(d_orb_cand_flat);
+        d_orb_cand = d_orb_cand_flat = nullptr;
         orb_cand_cap = 0;
         HIP_TRY(ctx, hipMalloc(&d_orb_cand, sizeof(uint32_t) * p.cand_total));
+        HIP_TRY(ctx, hipMalloc(&d_orb_cand_flat, sizeof(uint32_t) * p.cand_total));
         orb_cand_cap = p.cand_total;
+    }
+    if (p.count_total > orb_count_cap) {
+        if (d_orb_cand_count) (void)hipFree(d_orb_cand_count);
+        d_orb_cand_count = nullptr;
+        orb_count_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&d_orb_cand_count, sizeof(uint32_t) * p.count_total));
+        orb_count_cap = p.count_total;
     }
     const int lvl_need = batch * kOrbMaxLevels;
     if (lvl_need > orb_lvl_cap) {
-        for (void *q : {(void *)d_orb_cand_count, (void *)d_lvl_ras, (void *)d_lvl_resp, (void *)d_lvl_n})
+        for (void *q : {(void *)d_lvl_ras, (void *)d_lvl_resp, (void *)d_lvl_n})
             if (q) (void)hipFree(q);
-        d_orb_cand_count = d_lvl_ras = nullptr; d_lvl_resp = nullptr; d_lvl_n = nullptr;
+        d_lvl_ras = nullptr; d_lvl_resp = nullptr; d_lvl_n = nullptr;
         orb_lvl_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&d_orb_cand_count, sizeof(uint32_t) * lvl_need));
         HIP_TRY(ctx, hipMalloc(&d_lvl_ras, sizeof(uint32_t) * (size_t)lvl_need * kOrbLevelCap));
         HIP_TRY(ctx, hipMalloc(&d_lvl_resp, sizeof(float) * (size_t)lvl_need * kOrbLevelCap));
         HIP_TRY(ctx, hipMalloc(&d_lvl_n, sizeof(int) * lvl_need));
@@ -591,7 +599,6 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
 void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride, size_t src_frame_stride,
                                 int channels, int fast_threshold, int batch, int first_slot)
 {
-    (void)hipMemsetAsync(d_orb_cand_count, 0, sizeof(uint32_t) * orb.nlevels * batch, stream);
     mark(0);
     auto level = [&](uint8_t *base, int l) { return PlaneBatch{base + orb.lv[l].off, orb.lv[l].pitch, orb.frame_bytes}; };
     for (int l = 0; l < orb.nlevels; l++) {
@@ -604,10 +611,11 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
         launch_frontend(in, L.w, L.h, l == 0 ? src_stride : L.pitch, l == 0 ? src_frame_stride : orb.frame_bytes,
                         l == 0 ? channels : 1, l == 0 ? level(d_pyr, 0) : PlaneBatch{nullptr, 0, 0},
                         PlaneBatch{nullptr, 0, 0}, level(d_pyr_blur, l), fast_threshold, d_orb_cand + L.cand_off,
-                        d_orb_cand_count + (size_t)l * batch, L.cand_cap, batch, gc, stream);
+                        d_orb_cand_count + L.count_off, batch, gc, stream);
     }
     mark(1);
-    launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n, stream);
+    launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_orb_cand_flat, d_lvl_ras, d_lvl_resp,
+                      d_lvl_n, stream);
     launch_orb_finish(orb, batch, d_pyr, d_lvl_ras, d_lvl_resp, d_lvl_n, d_kps + (size_t)first_slot * kp_stride,
                       kp_stride, d_nkp + first_slot, stream);
     mark(2);

@@ -18,13 +18,13 @@ struct vo_ctx {
     size_t in_frame_bytes = 0;
     int kp_stride = 0;  // feature records per slot
     int slots = 0;      // feature slots (keypoints + descriptors + count)
-    int cand_cap = 0;   // NMS survivors per frame: at most one per 2x2 block
+    int max_tiles = 0;  // tiles of the fused image kernel in the largest frame
 
     uint8_t *d_in = nullptr;     // staging for frames handed over from the host
     uint8_t *d_gray = nullptr, *d_score = nullptr, *d_blur = nullptr;
     uint8_t *d_aux = nullptr;    // fourth plane of the image-processing operator (masked output)
     uint32_t *d_hist = nullptr;  // 256 bins + 256-byte equalisation table behind them
-    uint32_t *d_cand = nullptr, *d_cand_count = nullptr;
+    uint32_t *d_cand = nullptr, *d_cand_flat = nullptr, *d_cand_count = nullptr;  // [frame][tile][kTileCap], [frame][tile]
     vo_kp *d_kps = nullptr;
     uint8_t *d_desc = nullptr;
     int *d_nkp = nullptr;
@@ -45,10 +45,10 @@ struct vo_ctx {
     vo::OrbPlan orb{};
     int orb_w = 0, orb_h = 0, orb_features = 0, orb_batch = 0;
     float orb_scale = 0.f;
-    size_t orb_pyr_cap = 0, orb_cand_cap = 0;
+    size_t orb_pyr_cap = 0, orb_cand_cap = 0, orb_count_cap = 0;
     int orb_lvl_cap = 0;
     uint8_t *d_pyr = nullptr, *d_pyr_blur = nullptr;
-    uint32_t *d_orb_cand = nullptr, *d_orb_cand_count = nullptr, *d_lvl_ras = nullptr;
+    uint32_t *d_orb_cand = nullptr, *d_orb_cand_flat = nullptr, *d_orb_cand_count = nullptr, *d_lvl_ras = nullptr;
     float *d_lvl_resp = nullptr;
     int *d_lvl_n = nullptr;
     int8_t *d_pattern0 = nullptr;  // the unrotated 31x31 test pattern

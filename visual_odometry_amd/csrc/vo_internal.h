@@ -13,6 +13,9 @@ constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
 constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
 constexpr int kKnnSplits = 4;      // train-set splits per query block
 constexpr int kFBorder = 31;       // ORB edgeThreshold
+constexpr int kTileW = 128, kTileH = 16;  // tile of the fused image kernel
+constexpr int kTileCap = kTileW * kTileH / 4;  // corners one tile can emit (3x3 strict maxima: one per 2x2 block)
+inline int tiles_of(int w, int h) { return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
 constexpr int kOrbMaxLevels = 8;   // pyramid levels of the full ORB detector
 constexpr int kOrbLevelCap = 2048; // keypoints one level can contribute
 
@@ -33,16 +36,18 @@ struct OrbLevel {
     int w, h, pitch;   // level image; rows are `pitch` bytes apart
     int quota;         // keypoints wanted from this level
     float scale;       // level-0 pixels per level pixel
-    int cand_cap;      // FAST corners one frame can emit on this level
+    int tiles;         // tiles of the fused image kernel on this level
     size_t off;        // byte offset of the level inside a frame's pyramid
-    size_t cand_off;   // element offset of the level's candidate lists ([frame][cand_cap])
+    size_t cand_off;   // element offset of the level's corner lists ([frame][tiles][kTileCap])
+    size_t count_off;  // element offset of the level's per-tile corner counts ([frame][tiles])
 };
 
 // Geometry of the pyramid for one (frame size, scale factor, levels, nfeatures, batch).
 struct OrbPlan {
     int nlevels;
     size_t frame_bytes;  // bytes of one frame's pyramid (all levels, padded to whole tiles)
-    size_t cand_total;   // candidate-list elements for the whole batch
+    size_t cand_total;   // corner-list elements for the whole batch
+    size_t count_total;  // per-tile counters for the whole batch
     OrbLevel lv[kOrbMaxLevels];
 };
 
@@ -55,7 +60,8 @@ void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
 // per (level, frame): border filter, retainBest(2*quota) by FAST score, Harris
 // response, retainBest(quota); survivors in raster order
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
-                       const uint32_t *cand_count, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n, hipStream_t s);
+                       const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
+                       hipStream_t s);
 // concatenate the levels, intensity-centroid angle, cv::KeyPoint records
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
                        const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s);
@@ -72,22 +78,24 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride,
                  int batch, GrayCoeffs c, hipStream_t s);
 
 // Fused tile kernel: (optional BGR[A]->gray) + FAST-9/16 with 3x3 strict
-// non-max suppression + 7x7 fixed-point Gaussian.  Corners that survive the
-// suppression are appended to cand[frame*cand_cap ...] as keys
-// ((255-score) << 24) | (y*width + x) (cand_count must be zero on entry).
+// non-max suppression + 7x7 fixed-point Gaussian.  With T = tiles_of(width,
+// height), tile t of frame f writes its surviving corners to
+// cand[(f*T + t)*kTileCap ...] as keys ((255-score) << 24) | (y*width + x) and
+// their number to tile_count[f*T + t] (no initialisation needed).
 // Any of gray_out/score/blur may have base == 0, cand may be null; `score`
 // receives the per-pixel score map (diagnostic).
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
                      size_t src_frame_stride, int channels, PlaneBatch gray_out,
                      PlaneBatch score, PlaneBatch blur, int threshold,
-                     uint32_t *cand, uint32_t *cand_count, int cand_cap,
-                     int batch, GrayCoeffs c, hipStream_t s);
+                     uint32_t *cand, uint32_t *tile_count, int batch,
+                     GrayCoeffs c, hipStream_t s);
 
 // Keep the max_features best keys per frame (all of them, in raster order,
 // when there are not more than max_features), drop keypoints closer than
-// `border` px to the image edge, write vo_kp records.
-void launch_select(const uint32_t *cand, const uint32_t *cand_count,
-                   int cand_cap, int width, int height, int max_features,
+// `border` px to the image edge, write vo_kp records.  cand/tile_count as
+// written by launch_frontend; flat is scratch of the same size as cand.
+void launch_select(const uint32_t *cand, const uint32_t *tile_count, uint32_t *flat,
+                   int width, int height, int max_features,
                    int border, vo_kp *kps, int kp_stride, int *nkp,
                    int batch, hipStream_t s);
 
@@ -166,5 +174,52 @@ void launch_carry(vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int kp_stride,
 void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const int *info,
                     const int *bp_info, const int *pose, const double *rt, vo_frame_result *out, int batch,
                     hipStream_t s);
+
+#ifdef __HIPCC__
+// One block gathers the per-tile corner lists of a frame (tile t holds
+// count[t] keys at cand[t*kTileCap ...]) into the contiguous list `flat` and
+// returns its length.  s_off: LDS scratch for ntiles words, s_scan: THREADS
+// words.  Ends with a barrier: every thread may read flat[] afterwards.
+template <int THREADS>
+__device__ inline int flatten_tile_lists(const uint32_t *__restrict__ cand, const uint32_t *__restrict__ count,
+                                         int ntiles, uint32_t *__restrict__ flat, uint32_t *s_off,
+                                         uint32_t *s_scan)
+{
+    __shared__ uint32_t s_total;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < ntiles; t += THREADS) s_off[t] = min(count[t], (uint32_t)kTileCap);
+    __syncthreads();
+    const int per = (ntiles + THREADS - 1) / THREADS;
+    const int t0 = min(tid * per, ntiles), t1 = min(t0 + per, ntiles);
+    uint32_t sum = 0;
+    for (int t = t0; t < t1; t++) sum += s_off[t];
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < THREADS; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_scan[tid] - sum;
+    for (int t = t0; t < t1; t++) {
+        const uint32_t n = s_off[t];
+        s_off[t] = run;
+        run += n;
+    }
+    if (tid == THREADS - 1) s_total = s_scan[tid];
+    __syncthreads();
+    const uint32_t total = s_total;
+    const int lane = tid & 63;
+    for (int t = tid >> 6; t < ntiles; t += THREADS / 64) {
+        const uint32_t o = s_off[t];
+        const uint32_t n = (t + 1 < ntiles ? s_off[t + 1] : total) - o;
+        for (uint32_t j = lane; j < n; j += 64) flat[o + j] = cand[(size_t)t * kTileCap + j];
+    }
+    __threadfence_block();
+    __syncthreads();
+    return (int)total;
+}
+#endif
 
 }  // namespace vo
