@@ -67,13 +67,13 @@ def main():
     ap.add_argument("--streams", type=int, default=16, help="independent camera streams per GPU")
     ap.add_argument("--frames", type=int, default=16, help="consecutive frames per stream per step (even)")
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--contexts", type=int, default=2,
+    ap.add_argument("--contexts", type=int, default=1,
                     help="vo_ctx objects per GPU (each owns streams/contexts camera streams and one HIP "
                          "stream); batches of different contexts overlap on the GPU")
     ap.add_argument("--detector", choices=("orb", "fast"), default="orb",
                     help="orb: full ORB detector, 8-level pyramid; fast: FAST corners + ORB::compute on one "
                          "level, the sequence the reference node executes")
-    ap.add_argument("--cpu-frames", type=int, default=256, help="frames timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=192, help="frames timed for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -153,11 +153,26 @@ def main():
 
     if rank == 0:
         n_kp = float(res["n_keypoints"].mean())
-        cand_bytes = 4.0
-        # algorithmic work per launch (one launch covers the whole batch of B frames)
+        # Algorithmic work of one launch (= the whole batch of Bc frames of one context), per stage.
+        # Image stages are priced in HBM bytes: every input byte read once, every output byte written once.
+        px0 = W * H
+        if levels:
+            sizes = [ctx.orb_level_size(l) for l in range(levels)]
+            px_up = float(sum(a * b for a, b in sizes[1:]))
+            px_all = px0 + px_up
+            px_last = sizes[-1][0] * sizes[-1][1]
+        else:
+            px_up, px_all = 0.0, float(px0)
         work = {
-            "frontend_fast_nms_blur": ("hbm", Bc * W * H * (C + 1) / 1e9, HBM_PEAK_GBS, "GB/s"),
+            # level 0: read C bytes/pixel, write the blurred plane (+ the gray plane that feeds the pyramid)
+            "frontend_fast_nms_blur": ("hbm", Bc * px0 * (C + 1 + (1 if levels else 0)) / 1e9, HBM_PEAK_GBS, "GB/s"),
+            # levels 1..L-1: read the previous level, write the level
+            "pyramid_resize": ("hbm", Bc * (px_all - px_last + px_up) / 1e9 if levels else 0.0,
+                               HBM_PEAK_GBS, "GB/s"),
+            # levels 1..L-1: read the gray level, write its blurred version
+            "frontend_upper_levels": ("hbm", Bc * 2 * px_up / 1e9, HBM_PEAK_GBS, "GB/s"),
             "brief": ("hbm", Bc * n_kp * (512 + 32) / 1e9, HBM_PEAK_GBS, "GB/s"),
+            # 8 XOR + 8 popcount-accumulate 32-bit lane operations per descriptor pair
             "knn2": ("valu", Bc * n_kp * n_kp * 16 / 1e9, VALU_PEAK_GLOPS, "Glane-op/s"),
         }
         dominant = max(acc, key=acc.get)
@@ -167,31 +182,34 @@ def main():
             bound, amount, peak, unit = work[dominant]
             ach = amount / (acc[dominant] * 1e-3)
             roof.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
-        # the HBM-bound image kernel is reported in any case
-        b_, amount, peak, unit = work["frontend_fast_nms_blur"]
-        fe = amount / (acc["frontend_fast_nms_blur"] * 1e-3)
+        stage_roof = {}
+        for k, (bound, amount, peak, unit) in work.items():
+            if acc.get(k, 0.0) > 1e-4 and amount > 0:
+                a_ = amount / (acc[k] * 1e-3)
+                stage_roof[k] = {"bound": bound, "achieved": a_, "peak": peak, "unit": unit, "frac": a_ / peak}
         out = {
             "metric": "frames/sec (detect+match+RANSAC pose) @1280x720, 2000 kp",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int32 (image, match), f64 (RANSAC)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8/int32 (image, match), f32 (Harris, angle), f64 (RANSAC)",
+            "data": "synthetic",
             "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
                                    ("orb8level" if levels else "fast1level"),
+                       "detector": args.detector, "pyramid_levels": levels or 1,
                        "streams_per_gpu": S * NC, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
                        "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,
                        "parallelism": "independent streams, one process per GPU, no collective"},
             "roofline": roof,
-            "frontend_kernel": {"bound": "hbm", "achieved": fe, "peak": peak, "unit": unit, "frac": fe / peak,
-                                "ms_per_launch": acc["frontend_fast_nms_blur"]},
-            "stage_ms_per_step": {k: round(v, 4) for k, v in acc.items()},
+            "stage_roofline": stage_roof,
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in acc.items()},
             "mean_keypoints": n_kp, "mean_matches": float(res["n_matches"].mean()),
             "pose_success_rate": float(res["pnp_success"].mean()),
         }
         if world == 1 and args.cpu_frames > 0:
             cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": f"{args.cpu_frames} HD720 frames of the same stream, "
+                                   "sample": f"{args.cpu_frames} HD720 frames of the same stream and detector, "
                                              "oracle C pipeline, 1 thread"}
         print(json.dumps(out))
     for c in ctxs:

@@ -44,3 +44,17 @@ for i, n in enumerate(names):
     print(f"{n:32s} median {np.median(col):8.0f}  p90 {np.percentile(col, 90):8.0f} cycles")
 tot = t[ok, 9] - t[ok, 0]
 print(f"{'start -> end':32s} median {np.median(tot):8.0f}  p90 {np.percentile(tot, 90):8.0f} cycles")
+
+# ---- PnP kernel (one block per frame): thread 0 of the first 256 blocks
+pn = np.zeros((256, 16), np.uint64)
+raw.vo_debug_pnp_stamps.argtypes = [C.c_void_p]
+assert raw.vo_debug_pnp_stamps(pn.ctypes.data) == 0
+t = pn[:, :11].astype(np.int64)
+d = np.diff(t, axis=1)
+names = ["load points", "rng window + subsets (last round)", "EPnP hypotheses (last round)",
+         "score + accept (last round)", "inlier mask + list", "planarity", "DLT sums", "12x12 singular vectors",
+         "polar + Rodrigues", "Levenberg-Marquardt"]
+print("PnP, RANSAC loop total (stamp 1 -> 4): median", np.median(t[:, 4] - t[:, 1]))
+for i, n in enumerate(names):
+    print(f"{n:36s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
+print(f"{'whole kernel':36s} median {np.median(t[:, 10] - t[:, 0]):9.0f}")

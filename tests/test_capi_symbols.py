@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
     # the Python binding covers the same set
     assert sorted(capi.EXPORTS) == names
     assert capi.load().vo_abi_version() == 1
-    assert capi.load().vo_batch_stage_count() == 10
+    assert capi.load().vo_batch_stage_count() == 12
 
 
 def test_struct_layouts_match_header():

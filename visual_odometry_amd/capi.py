@@ -212,6 +212,12 @@ class Context:
                                             fast_threshold, _ptr(kps), _ptr(desc), cap, C.addressof(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def orb_level_size(self, level: int):
+        """(width, height) of pyramid level `level` of the last ORB detection / configuration."""
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self._lib.vo_orb_get_level(self._h, 0, level, 0, None, 0, C.addressof(w), C.addressof(h)))
+        return w.value, h.value
+
     def orb_level(self, frame: int, level: int, blurred=False) -> np.ndarray:
         w, h = C.c_int(0), C.c_int(0)
         self._check(self._lib.vo_orb_get_level(self._h, frame, level, int(blurred), None, 0, C.addressof(w),

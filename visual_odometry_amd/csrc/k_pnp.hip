@@ -787,6 +787,22 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     }
 }
 
+#ifdef VO_FE_STAMPS
+// Diagnostic build only: cycle stamps of thread 0 of the first 256 blocks.
+__device__ unsigned long long g_pnp_stamps[256 * 16];
+#define PNP_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256)                                        \
+            g_pnp_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+extern "C" int vo_debug_pnp_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_stamps), sizeof(unsigned long long) * 256 * 16);
+}
+#else
+#define PNP_STAMP(i) do { } while (0)
+#endif
+
 // out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec
 __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__restrict__ valid,
                                                            const float *__restrict__ pts3,
@@ -812,6 +828,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     int *po = pose + b * 4;
     double *rto = rt + (size_t)b * 6;
 
+    PNP_STAMP(0);
     if (tid < 6) rto[tid] = 0;
     // reference src/frame_processor.cpp:176-177 asks for >= 4 points; with 4
     // OpenCV switches to P3P, which is not provided: report failure below 5
@@ -848,6 +865,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         return;
     }
 
+    PNP_STAMP(1);
     // ---------------- RANSAC rounds ----------------
     while (true) {
         const long long pos = S.pos;
@@ -872,6 +890,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
             if (nc == 0) S.done = 1;  // RNG table exhausted
         }
         __syncthreads();
+        PNP_STAMP(2);
         const int nc = S.nchunk;
         {
             const int h = tid / PR_GROUP;
@@ -879,6 +898,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
             if ((wave * (kWave / PR_GROUP)) < nc) solve_hypothesis(S, obj, img, h, h < nc, fx, fy, cx, cy);
         }
         __syncthreads();
+        PNP_STAMP(3);
         for (int h = wave; h < nc; h += PR_WAVES) {
             if (!S.ok[h]) continue;
             double R[9];
@@ -907,6 +927,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
             if (S.iter >= S.niters) S.done = 1;
         }
         __syncthreads();
+        PNP_STAMP(4);
         if (S.done) break;
     }
 
@@ -946,6 +967,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         }
     }
     const int k = S.scan_base;  // inlier count
+    PNP_STAMP(5);
 
     // ---------------- refinement: solvePnP(SOLVEPNP_ITERATIVE) on inliers ----
     bool init_ok = k >= 6;
@@ -978,6 +1000,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         __syncthreads();
         init_ok = S.lm_ok != 0;
     }
+    PNP_STAMP(6);
     if (init_ok) {
         // DLT: L^T L has the block form [[P, 0, Px], [0, P, Py], [Px, Py, Pxy]]
         // with P = sum m m^T, m = (X, Y, Z, 1); x, y = minus the normalised image point
@@ -1001,6 +1024,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
                 }
         }
         block_reduce<40>(S, acc);
+        PNP_STAMP(7);
         if (wave == 0) {
             // column gl of the symmetric 12 x 12 matrix, then its singular vectors
             const int gl = lane & (PR_GROUP - 1);
@@ -1027,6 +1051,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
             }
         }
         __syncthreads();
+        PNP_STAMP(8);
         if (tid == 0) {
             const double *RRt = S.null12;
             double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
@@ -1055,6 +1080,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         init_ok = S.lm_ok != 0;
     }
 
+    PNP_STAMP(9);
     if (init_ok) {
         // CvLevMarq: <= 20 iterations, epsilon FLT_EPSILON, lambda = 10^lambdaLg10
         const int max_iter = 20;
@@ -1163,6 +1189,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         }
     }
     __syncthreads();
+    PNP_STAMP(10);
     if (tid == 0) {
         // refinement unavailable (planar / < 6 inliers): OpenCV reports failure
         // and hands back the best RANSAC hypothesis

@@ -194,15 +194,15 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
                           b.fast_threshold, B, /*first_slot=*/S);
     c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
-    c->mark(6);
+    c->mark(8);
     launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
                       c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
-    c->mark(7);
+    c->mark(9);
     launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
                               c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
                               depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
                               c->d_bpinfo, B, c->stream);
-    c->mark(8);
+    c->mark(10);
     if (!(b.enable_pose && dsrc)) {
         HIP_TRY(c, hipMemsetAsync(c->d_pose, 0, sizeof(int) * 4 * B, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_rt, 0, sizeof(double) * 6 * B, c->stream));
@@ -210,13 +210,13 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
                           b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
                           c->d_rt, B, c->stream);
-    c->mark(9);
+    c->mark(11);
     launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
                    c->stream);
     launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
     HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost,
                               c->stream));
-    c->mark(10);
+    c->mark(12);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));
     c->submitted = true;
@@ -273,8 +273,8 @@ int vo_batch_wait(vo_ctx *c, vo_frame_result *results)
 }
 
 static const char *const kStageNames[vo_ctx::kStages] = {
-    "frontend_fast_nms_blur", "select_topn", "brief", "knn2", "match_finalize", "f_ransac",
-    "track_ages", "filter_backproject", "pnp_ransac", "collect_carry"};
+    "frontend_fast_nms_blur", "pyramid_resize", "frontend_upper_levels", "select_topn", "brief", "knn2",
+    "match_finalize", "f_ransac", "track_ages", "filter_backproject", "pnp_ransac", "collect_carry"};
 
 int vo_batch_set_timing(vo_ctx *c, int enable)
 {

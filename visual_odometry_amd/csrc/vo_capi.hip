@@ -534,9 +534,11 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
                     PlaneBatch{nullptr, 0, 0}, plane(d_blur), fast_threshold, d_cand, d_cand_count, batch, gc,
                     stream);
     mark(1);
+    mark(2);  // no pyramid in this mode
+    mark(3);
     launch_select(d_cand, d_cand_count, d_cand_flat, w, h, max_features, kFBorder,
                   d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot, batch, stream);
-    mark(2);
+    mark(4);
     launch_brief(plane(d_blur), d_kps + (size_t)first_slot * kp_stride, kp_stride, d_nkp + first_slot,
                  d_pattern, d_desc + (size_t)first_slot * kp_stride * 32, batch, stream);
 }
@@ -601,40 +603,44 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
 {
     mark(0);
     auto level = [&](uint8_t *base, int l) { return PlaneBatch{base + orb.lv[l].off, orb.lv[l].pitch, orb.frame_bytes}; };
-    for (int l = 0; l < orb.nlevels; l++) {
+    auto fast_level = [&](int l) {
         const OrbLevel &L = orb.lv[l];
-        if (l > 0)
-            launch_resize_exact(level(d_pyr, l - 1), orb.lv[l - 1].w, orb.lv[l - 1].h, level(d_pyr, l), L.w, L.h,
-                                batch, stream);
-        // level 0 converts to gray on the way in and keeps the gray plane for the next level
+        // level 0 converts to gray on the way in and keeps the gray plane for the pyramid
         const uint8_t *in = l == 0 ? src : d_pyr + L.off;
         launch_frontend(in, L.w, L.h, l == 0 ? src_stride : L.pitch, l == 0 ? src_frame_stride : orb.frame_bytes,
                         l == 0 ? channels : 1, l == 0 ? level(d_pyr, 0) : PlaneBatch{nullptr, 0, 0},
                         PlaneBatch{nullptr, 0, 0}, level(d_pyr_blur, l), fast_threshold, d_orb_cand + L.cand_off,
                         d_orb_cand_count + L.count_off, batch, gc, stream);
-    }
+    };
+    fast_level(0);
     mark(1);
+    for (int l = 1; l < orb.nlevels; l++)
+        launch_resize_exact(level(d_pyr, l - 1), orb.lv[l - 1].w, orb.lv[l - 1].h, level(d_pyr, l), orb.lv[l].w,
+                            orb.lv[l].h, batch, stream);
+    mark(2);
+    for (int l = 1; l < orb.nlevels; l++) fast_level(l);
+    mark(3);
     launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_orb_cand_flat, d_lvl_ras, d_lvl_resp,
                       d_lvl_n, stream);
     launch_orb_finish(orb, batch, d_pyr, d_lvl_ras, d_lvl_resp, d_lvl_n, d_kps + (size_t)first_slot * kp_stride,
                       kp_stride, d_nkp + first_slot, stream);
-    mark(2);
+    mark(4);
     launch_brief_steered(orb, batch, d_pyr_blur, d_kps + (size_t)first_slot * kp_stride, kp_stride,
                          d_nkp + first_slot, d_pattern0, d_desc + (size_t)first_slot * kp_stride * 32, stream);
 }
 
 void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacParams prm)
 {
-    mark(3);
+    mark(5);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
                 pairs, stream);
     if (cross_check)  // the same pairs with the roles of query and train swapped
         launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_tslot, d_qslot, kp_stride, d_partial_rev, kp_stride,
                     pairs, stream);
-    mark(4);
+    mark(6);
     launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio,
                           cross_check ? d_partial_rev : nullptr, d_knn, d_good, d_ngood, pairs, stream);
-    mark(5);
+    mark(7);
     launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
                     stream);
 }

@@ -72,7 +72,7 @@ struct vo_ctx {
     int empty_slot = 0;            // feature slot that always holds 0 keypoints
 
     // optional per-stage timing of the batched pipeline (HIP events on `stream`)
-    static constexpr int kStages = 10;
+    static constexpr int kStages = 12;
     bool timing = false;
     hipEvent_t ev[kStages + 1] = {};
     void mark(int i)
