@@ -16,59 +16,44 @@ namespace vo {
 
 namespace {
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------ resize
 
 constexpr int RZ_TW = 128, RZ_TH = 16, RZ_THREADS = 256;
 constexpr int RZ_FP = 272;    // LDS footprint row pitch (bytes): scale <= 2 plus alignment slack
 constexpr int RZ_FROWS = 36;  // footprint rows
 
-// One axis entry of cv::resize(INTER_LINEAR_EXACT): source offset and the 8.8
-// weight of the second tap; scale = 1 / (dst/src) in double, sample position
-// scale * (d + 0.5) - 0.5, replicate outside [0, src-1).
-__device__ __forceinline__ void rz_axis(int d, int src_n, int dst_n, int &ofs, int &w1)
+// Source bytes p[xo], p[xo + 1] of a staged row as a pair of u16, where the
+// row's dwords r0, r1, r2 start `rel` (0..10) bytes before p[xo].
+__device__ __forceinline__ us2 rz_pick2(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t rel)
 {
-    const double inv_scale = (double)dst_n / (double)src_n;
-    const double scale = 1.0 / inv_scale;
-    const double f = scale * ((double)d + 0.5) - 0.5;
-    const int i = (int)floor(f);
-    if (i >= 0 && src_n > 1) {
-        if (i < src_n - 1) {
-            ofs = i;
-            w1 = (int)rint((f - (double)i) * 256.0);
-        } else {
-            ofs = src_n - 1;
-            w1 = 0;
-        }
-    } else {
-        ofs = 0;
-        w1 = 0;
-    }
+    const uint32_t lo = rel < 4 ? r0 : (rel < 8 ? r1 : r2);
+    const uint32_t hi = rel < 4 ? r1 : (rel < 8 ? r2 : 0u);
+    const uint32_t a = __builtin_amdgcn_alignbyte(hi, lo, rel & 3u);
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, a, 0x0c010c00u));
 }
 
-// Level l from level l-1 for every frame of the batch.  One 128x16 output tile
-// per block; the source footprint is staged in LDS with dword loads.
+// Level l from level l-1 for every frame of the batch: cv::resize(...,
+// INTER_LINEAR_EXACT) -- rows in 8.8 fixed point, columns in 16.16,
+// (v + 2^15) >> 16.  xtab/ytab hold per destination column/row the source
+// offset (low 16 bits) and the 8.8 weight of the second tap (high 16 bits),
+// built on the host by orb_axis_table().  One 128x16 output tile per block;
+// the source footprint is staged in LDS with dword loads; a thread computes
+// the same four columns of two rows (three LDS dwords per source row).
 __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
-                                                            int dh)
+                                                            int dh, const uint32_t *__restrict__ xtab,
+                                                            const uint32_t *__restrict__ ytab)
 {
-    __shared__ int s_xo[RZ_TW], s_xw[RZ_TW], s_yo[RZ_TH], s_yw[RZ_TH];
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP];
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * RZ_TW, y0 = blockIdx.y * RZ_TH, f = blockIdx.z;
-    if (tid < RZ_TW) {
-        int o, w;
-        rz_axis(min(x0 + tid, dw - 1), sw, dw, o, w);
-        s_xo[tid] = o;
-        s_xw[tid] = w;
-    } else if (tid < RZ_TW + RZ_TH) {
-        int o, w;
-        rz_axis(min(y0 + tid - RZ_TW, dh - 1), sh, dh, o, w);
-        s_yo[tid - RZ_TW] = o;
-        s_yw[tid - RZ_TW] = w;
-    }
-    __syncthreads();
-    const int sx_lo = s_xo[0] & ~3, sx_hi = min(s_xo[RZ_TW - 1] + 1, sw - 1);
-    const int sy_lo = s_yo[0], sy_hi = min(s_yo[RZ_TH - 1] + 1, sh - 1);
+    // block-uniform footprint (tables are padded to whole tiles with their last entry)
+    const int sx_lo = (int)(xtab[x0] & 0xffffu) & ~3;
+    const int sx_hi = min((int)(xtab[x0 + RZ_TW - 1] & 0xffffu) + 1, sw - 1);
+    const int sy_lo = (int)(ytab[y0] & 0xffffu);
+    const int sy_hi = min((int)(ytab[y0 + RZ_TH - 1] & 0xffffu) + 1, sh - 1);
     const int cols4 = (sx_hi - sx_lo) / 4 + 1, rows = sy_hi - sy_lo + 1;  // host checked: fits the LDS footprint
     const uint8_t *sp = src.base + f * src.plane_stride;
     for (int i = tid; i < rows * cols4; i += RZ_THREADS) {
@@ -76,26 +61,42 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
         *reinterpret_cast<uint32_t *>(&s_src[r * RZ_FP + c4 * 4]) =
             *reinterpret_cast<const uint32_t *>(sp + (size_t)(sy_lo + r) * src.pitch + sx_lo + c4 * 4);
     }
+    // this thread's four columns
+    const int lx = (tid & 31) * 4;
+    const uint4 xt = *reinterpret_cast<const uint4 *>(xtab + x0 + lx);
+    const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
+    const uint32_t base = (xe[0] & 0xffffu) & ~3u;  // first staged byte this thread reads
+    uint32_t rel[4];
+    us2 wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        rel[j] = (xe[j] & 0xffffu) - base;
+        const uint32_t w1 = xe[j] >> 16;
+        wx[j] = __builtin_bit_cast(us2, (256u - w1) | (w1 << 16));
+    }
     __syncthreads();
 
     uint8_t *dp = dst.base + f * dst.plane_stride;
-    for (int q = tid; q < RZ_TW * RZ_TH / 4; q += RZ_THREADS) {
-        const int ly = q / (RZ_TW / 4), lx = (q - ly * (RZ_TW / 4)) * 4;
-        const int gy = y0 + ly, gx = x0 + lx;
+    const int gx = x0 + lx;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int ly = (tid >> 5) + half * (RZ_TH / 2), gy = y0 + ly;
         if (gy >= dh || gx >= dw) continue;
-        const int yo = s_yo[ly];
-        const uint8_t *r0 = &s_src[(yo - sy_lo) * RZ_FP];
-        const uint8_t *r1 = &s_src[(min(yo + 1, sh - 1) - sy_lo) * RZ_FP];
-        const uint32_t wy1 = (uint32_t)s_yw[ly], wy0 = 256u - wy1;
+        const uint32_t ye = ytab[gy];
+        const int yo = (int)(ye & 0xffffu);
+        const uint32_t wy1 = ye >> 16;
+        const us2 wy = __builtin_bit_cast(us2, (256u - wy1) | (wy1 << 16));
+        const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&s_src[(yo - sy_lo) * RZ_FP + (base - sx_lo)]);
+        const uint32_t *r1 =
+            reinterpret_cast<const uint32_t *>(&s_src[(min(yo + 1, sh - 1) - sy_lo) * RZ_FP + (base - sx_lo)]);
+        const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
         uint32_t out = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int xo = s_xo[lx + j];
-            const int a = xo - sx_lo, b = min(xo + 1, sw - 1) - sx_lo;
-            const uint32_t wx1 = (uint32_t)s_xw[lx + j], wx0 = 256u - wx1;
-            const uint32_t h0 = wx0 * r0[a] + wx1 * r0[b];
-            const uint32_t h1 = wx0 * r1[a] + wx1 * r1[b];
-            out |= ((wy0 * h0 + wy1 * h1 + 32768u) >> 16) << (8 * j);
+            const uint32_t h0 = __builtin_amdgcn_udot2(rz_pick2(a0, a1, a2, rel[j]), wx[j], 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot2(rz_pick2(b0, b1, b2, rel[j]), wx[j], 0u, false);
+            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, h0 | (h1 << 16)), wy, 32768u, false);
+            out |= (v >> 16) << (8 * j);
         }
         *reinterpret_cast<uint32_t *>(dp + (size_t)gy * dst.pitch + gx) = out;  // pitch is padded
     }
@@ -450,7 +451,7 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
     const float factor = (float)(1.0 / scale_factor);
     float per = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
     int sum = 0;
-    size_t off = 0, coff = 0, noff = 0;
+    size_t off = 0, coff = 0, noff = 0, toff = 0;
     for (int l = 0; l < nlevels; l++) {
         OrbLevel &L = p.lv[l];
         L.scale = (float)pow((double)scale_factor, (double)l);
@@ -474,6 +475,10 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
         coff += (size_t)L.tiles * kTileCap * batch;
         L.count_off = noff;
         noff += (size_t)L.tiles * batch;
+        L.xtab_off = toff;
+        toff += (size_t)L.pitch;
+        L.ytab_off = toff;
+        toff += (size_t)((L.h + 15) / 16 * 16);
         if (l > 0) {
             // the resize kernel's LDS footprint of one 128x16 output tile
             const OrbLevel &S = p.lv[l - 1];
@@ -484,14 +489,41 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
     p.frame_bytes = off;
     p.cand_total = coff;
     p.count_total = noff;
+    p.tab_total = toff;
     *out = p;
     return true;
 }
 
-void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, int batch, hipStream_t s)
+// One axis of cv::resize(INTER_LINEAR_EXACT) as a table: entry d = source
+// offset | (8.8 weight of the second tap) << 16, with scale = 1 / (dst/src) in
+// double, sample position scale * (d + 0.5) - 0.5 and replication outside
+// [0, src-1); padded to `padded` entries with the last one.
+void orb_axis_table(int src_n, int dst_n, int padded, uint32_t *out)
+{
+    const double inv_scale = (double)dst_n / (double)src_n;
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < padded; d++) {
+        const int dd = d < dst_n ? d : dst_n - 1;
+        const double f = scale * ((double)dd + 0.5) - 0.5;
+        const int i = (int)floor(f);
+        uint32_t ofs = 0, w1 = 0;
+        if (i >= 0 && src_n > 1) {
+            if (i < src_n - 1) {
+                ofs = (uint32_t)i;
+                w1 = (uint32_t)lrint((f - (double)i) * 256.0);
+            } else {
+                ofs = (uint32_t)(src_n - 1);
+            }
+        }
+        out[d] = ofs | (w1 << 16);
+    }
+}
+
+void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, const uint32_t *xtab,
+                         const uint32_t *ytab, int batch, hipStream_t s)
 {
     dim3 grid((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, batch);
-    hipLaunchKernelGGL(k_resize_exact, grid, dim3(RZ_THREADS), 0, s, src, sw, sh, dst, dw, dh);
+    hipLaunchKernelGGL(k_resize_exact, grid, dim3(RZ_THREADS), 0, s, src, sw, sh, dst, dw, dh, xtab, ytab);
 }
 
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,

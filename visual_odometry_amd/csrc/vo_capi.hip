@@ -189,7 +189,7 @@ int vo_ctx::allocate()
 void vo_ctx::release()
 {
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_flat, d_cand_count, d_orb_cand_flat, d_kps, d_desc, d_nkp, d_pattern,
-                    d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0,
+                    d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0, d_orb_tab,
                     d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results};
@@ -593,6 +593,21 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
         HIP_TRY(ctx, hipMalloc(&d_lvl_n, sizeof(int) * lvl_need));
         orb_lvl_cap = lvl_need;
     }
+    if (p.tab_total > orb_tab_cap) {
+        if (d_orb_tab) (void)hipFree(d_orb_tab);
+        d_orb_tab = nullptr;
+        orb_tab_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&d_orb_tab, sizeof(uint32_t) * p.tab_total));
+        orb_tab_cap = p.tab_total;
+    }
+    {
+        std::vector<uint32_t> tab(p.tab_total, 0u);
+        for (int l = 1; l < p.nlevels; l++) {
+            orb_axis_table(p.lv[l - 1].w, p.lv[l].w, p.lv[l].pitch, tab.data() + p.lv[l].xtab_off);
+            orb_axis_table(p.lv[l - 1].h, p.lv[l].h, (p.lv[l].h + 15) / 16 * 16, tab.data() + p.lv[l].ytab_off);
+        }
+        HIP_TRY(ctx, hipMemcpy(d_orb_tab, tab.data(), sizeof(uint32_t) * p.tab_total, hipMemcpyHostToDevice));
+    }
     orb = p;
     orb_w = w; orb_h = h; orb_scale = scale_factor; orb_features = nfeatures; orb_batch = batch;
     return VO_OK;
@@ -616,7 +631,7 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
     mark(1);
     for (int l = 1; l < orb.nlevels; l++)
         launch_resize_exact(level(d_pyr, l - 1), orb.lv[l - 1].w, orb.lv[l - 1].h, level(d_pyr, l), orb.lv[l].w,
-                            orb.lv[l].h, batch, stream);
+                            orb.lv[l].h, d_orb_tab + orb.lv[l].xtab_off, d_orb_tab + orb.lv[l].ytab_off, batch, stream);
     mark(2);
     for (int l = 1; l < orb.nlevels; l++) fast_level(l);
     mark(3);

@@ -52,6 +52,8 @@ struct vo_ctx {
     float *d_lvl_resp = nullptr;
     int *d_lvl_n = nullptr;
     int8_t *d_pattern0 = nullptr;  // the unrotated 31x31 test pattern
+    uint32_t *d_orb_tab = nullptr;  // resize tables of all levels
+    size_t orb_tab_cap = 0;
 
     // pose stage
     float *d_depth = nullptr;  // staging for depth handed over from the host

@@ -40,6 +40,7 @@ struct OrbLevel {
     size_t off;        // byte offset of the level inside a frame's pyramid
     size_t cand_off;   // element offset of the level's corner lists ([frame][tiles][kTileCap])
     size_t count_off;  // element offset of the level's per-tile corner counts ([frame][tiles])
+    size_t xtab_off, ytab_off;  // element offsets of the level's resize tables (pitch / padded-height entries)
 };
 
 // Geometry of the pyramid for one (frame size, scale factor, levels, nfeatures, batch).
@@ -48,6 +49,7 @@ struct OrbPlan {
     size_t frame_bytes;  // bytes of one frame's pyramid (all levels, padded to whole tiles)
     size_t cand_total;   // corner-list elements for the whole batch
     size_t count_total;  // per-tile counters for the whole batch
+    size_t tab_total;    // resize-table entries of all levels
     OrbLevel lv[kOrbMaxLevels];
 };
 
@@ -55,8 +57,11 @@ struct OrbPlan {
 // (1 < scale_factor <= 2, 1..8 levels, smallest level >= 7 px, quota per level <= 1792)
 bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch, OrbPlan *out);
 
-// cv::resize(INTER_LINEAR_EXACT) of every plane of `src` into `dst`
-void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, int batch, hipStream_t s);
+// per-axis table of cv::resize(INTER_LINEAR_EXACT): offset | weight << 16, `padded` entries
+void orb_axis_table(int src_n, int dst_n, int padded, uint32_t *out);
+// cv::resize(INTER_LINEAR_EXACT) of every plane of `src` into `dst` (tables in device memory)
+void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, const uint32_t *xtab,
+                         const uint32_t *ytab, int batch, hipStream_t s);
 // per (level, frame): border filter, retainBest(2*quota) by FAST score, Harris
 // response, retainBest(quota); survivors in raster order
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
