@@ -123,7 +123,10 @@ int vo_knn2_hamming(vo_ctx *ctx, const uint8_t *query, int n_query,
  * with max_iters (OpenCV default 1000) and cv::RNG seed 2^64-1.
  * p1, p2: n x 2 float32; mask: n bytes; F: 9 doubles row-major.
  * *found is 0 when no model with more than 6 inliers exists (mask all 0).
- * Fewer than 15 points (OpenCV's LMedS branch) -> VO_ERR_UNSUPPORTED.
+ * With 8..14 points OpenCV runs its LMedS estimator instead (least median
+ * error, threshold derived from that median) and so does this call; the mask
+ * is then written even when *found is 0 (fewer than 7 inliers), as OpenCV
+ * leaves it.  Fewer than 8 points -> VO_ERR_UNSUPPORTED.
  * reference src/feature_matcher.cpp:52-58 */
 int vo_find_fundamental_ransac(vo_ctx *ctx, const float *p1, const float *p2,
                                int n, double threshold, double confidence,

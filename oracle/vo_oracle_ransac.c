@@ -290,10 +290,64 @@ static int get_subset_2d(const float *p1, const float *p2, int count, int m,
     return 0;
 }
 
+static int cmp_float_asc(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* [OCV-recall] LMeDSPointSetRegistrator::run (ptsetreg.cpp), what
+ * findFundamentalMat(FM_RANSAC) runs below 15 points: a fixed number of
+ * iterations for 45 % outliers, the model with the smallest median error
+ * (element count/2 of the sorted errors) wins, inliers are the points within
+ * sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(median).  The mask is
+ * written even when fewer than 7 inliers remain (the call then reports
+ * failure), as OpenCV does. */
+static int find_fundamental_lmeds(const float *p1, const float *p2, int n, double conf, int max_iters,
+                                  uint8_t *mask, double *F, int *iters_run)
+{
+    const int model_points = 7;
+    ora_rng rng = {(uint64_t)-1};
+    int niters = ransac_update_num_iters(conf, 0.45, model_points, max_iters);
+    if (niters < 3) niters = 3;
+    double min_median = DBL_MAX, best[9] = {0};
+    float err[16], sorted[16], ms1[14], ms2[14];
+    double models[27];
+    int iter;
+    for (iter = 0; iter < niters; iter++) {
+        if (!get_subset_2d(p1, p2, n, model_points, ms1, ms2, &rng, 10000, 1)) {
+            if (iter == 0) return 0;
+            break;
+        }
+        const int nmodels = ora_f7(ms1, ms2, models);
+        if (nmodels <= 0) continue;
+        for (int k = 0; k < nmodels; k++) {
+            ora_f_error(p1, p2, n, models + 9 * k, err);
+            memcpy(sorted, err, sizeof(float) * (size_t)n);
+            qsort(sorted, (size_t)n, sizeof(float), cmp_float_asc);
+            const double median = sorted[n / 2];
+            if (median < min_median) {
+                min_median = median;
+                memcpy(best, models + 9 * k, sizeof(best));
+            }
+        }
+    }
+    if (iters_run) *iters_run = iter;
+    if (!(min_median < DBL_MAX)) return 0;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - model_points)) * sqrt(min_median);
+    if (sigma < 0.001) sigma = 0.001;
+    const float t = (float)(sigma * sigma);
+    ora_f_error(p1, p2, n, best, err);
+    int good = 0;
+    for (int i = 0; i < n; i++) { mask[i] = (uint8_t)(err[i] <= t); good += mask[i]; }
+    memcpy(F, best, sizeof(best));
+    return good >= model_points;
+}
+
 /* [OCV-recall] findFundamentalMat(FM_RANSAC) -> RANSACPointSetRegistrator::run
- * with modelPoints 7, seed (uint64)-1, threshold compared squared in float.
- * Below 15 points OpenCV switches to LMedS, which is not restated: 0 is
- * returned with an all-zero mask. */
+ * with modelPoints 7, seed (uint64)-1, threshold compared squared in float;
+ * with 8..14 points the LMedS estimator above (the reference never passes
+ * fewer than 8, src/feature_matcher.cpp:52). */
 int ora_find_fundamental_ransac(const float *p1, const float *p2, int n,
                                 double thr, double conf, int max_iters,
                                 uint8_t *mask, double *F, int *iters_run)
@@ -301,9 +355,10 @@ int ora_find_fundamental_ransac(const float *p1, const float *p2, int n,
     const int model_points = 7;
     if (iters_run) *iters_run = 0;
     memset(mask, 0, (size_t)(n > 0 ? n : 0));
-    if (n < 15) return 0;
+    if (n < 8) return 0;
     if (thr <= 0) thr = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
+    if (n < 15) return find_fundamental_lmeds(p1, p2, n, conf, 1000, mask, F, iters_run);
 
     ora_rng rng = {(uint64_t)-1};
     int niters = max_iters > 1 ? max_iters : 1;

@@ -34,8 +34,8 @@ raw.vo_debug_fe_stamps.argtypes = [C.c_void_p]
 assert raw.vo_debug_fe_stamps(out.ctypes.data) == 0
 t = out[:, :10].astype(np.int64)
 d = np.diff(t, axis=1)
-names = ["issue loads", "wait loads + gray + LDS write", "barrier 1", "pre-test + wave queue", "score",
-         "blur row pass", "barrier 2", "NMS + emit", "blur column pass + outputs"]
+names = ["issue loads", "wait loads + gray + LDS write", "barrier 1", "pre-test + queue", "barrier 2",
+         "score / blur row pass", "barrier 3", "NMS + emit", "blur column pass + outputs"]
 ok = (t[:, 9] > 0)
 print("blocks with stamps:", int(ok.sum()))
 for i, n in enumerate(names):

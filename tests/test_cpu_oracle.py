@@ -216,8 +216,19 @@ def test_fundamental_ransac_labels_outliers(oracle):
 def test_fundamental_ransac_small_sets(oracle):
     rng = np.random.default_rng(23)
     cam, X, R, rv, t, p1, p2 = _two_view(rng, 14)
+    # 8..14 points: the LMedS estimator -- 300 iterations for 45 % outliers at 0.99 confidence,
+    # noise-free data: zero median, every point an inlier at the 0.001 px floor
     ok, F, mask, iters = oracle.find_fundamental_ransac(p1, p2)
-    assert not ok and mask.sum() == 0  # < 15 points: LMedS branch, not restated
+    assert ok and iters == 300 and mask.sum() >= 12
+    err = oracle.f_error(p1, p2, F)
+    assert np.median(err) < 1e-4
+    # gross outliers on 3 of 14 points are rejected, the median rule keeps at least half
+    p2o = p2.copy(); p2o[:3] += 80
+    ok, F, mask, iters = oracle.find_fundamental_ransac(p1, p2o)
+    assert ok and mask[:3].sum() == 0 and mask.sum() >= 7
+    # below 8 points the reference does not call findFundamentalMat
+    ok, F, mask, iters = oracle.find_fundamental_ransac(p1[:7], p2[:7])
+    assert not ok and mask.sum() == 0
 
 
 def test_rodrigues_roundtrip(oracle):

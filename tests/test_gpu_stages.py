@@ -222,3 +222,37 @@ def test_detect_orb_flat_and_tiny(ctx, oracle):
         ctx.detect_orb(np.zeros((20, 20), np.uint8), 500, 1.2, 8, 20)  # level 7 would be 6 px
     with pytest.raises(Exception):
         ctx.detect_orb(flat, 500, 2.5, 4, 20)
+
+
+@pytest.mark.parametrize("n,n_out", [(8, 0), (9, 1), (12, 2), (14, 3), (14, 0)])
+def test_find_fundamental_small_sets_take_lmeds(ctx, oracle, n, n_out):
+    """8..14 correspondences: cv::findFundamentalMat(FM_RANSAC) switches to LMedS."""
+    rng = np.random.default_rng(100 * n + n_out)
+    X = np.c_[rng.uniform(-2000, 2000, n), rng.uniform(-1500, 1500, n), rng.uniform(3000, 9000, n)]
+    ang = 0.03
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([120.0, -30.0, 40.0])
+    def proj(P):
+        return np.c_[700 * P[:, 0] / P[:, 2] + 640, 700 * P[:, 1] / P[:, 2] + 360]
+    p1 = (proj(X) + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    p2 = (proj(X @ R.T + t) + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    p2[:n_out] += rng.uniform(40, 90, (n_out, 2)).astype(np.float32)
+    ok_r, F_r, mask_r, it_r = oracle.find_fundamental_ransac(p1, p2)
+    ok, F, mask, it = ctx.find_fundamental_ransac(p1, p2)
+    assert ok == ok_r and it == it_r and np.array_equal(mask, mask_r)
+    assert it_r >= 3 and mask_r.sum() >= 7
+    assert np.abs(F - F_r).max() <= 1e-9 * np.abs(F_r).max()
+
+
+def test_match_features_with_few_survivors(ctx, oracle, vga_seq):
+    """A sparse pair (8..14 ratio survivors) still yields matches, through the LMedS branch."""
+    k0, d0, k1, d1, _ = _pair_points(oracle, vga_seq)
+    fwd = oracle.knn2(d0, d1)
+    good = oracle.ratio_test(fwd, len(k1), 0.7, k0, k1)
+    keep = good["query"][:11]
+    ks, ds = k0[keep], d0[keep]
+    knn = oracle.knn2(ds, d1)
+    m_ref, _, n_ratio = oracle.match_filter(knn, len(k1), ks, k1, 0.7)
+    assert 8 <= n_ratio <= 14 and len(m_ref) >= 7
+    m = ctx.match(ks, ds, k1, d1, 0.7)
+    assert np.array_equal(m, m_ref)

@@ -84,10 +84,9 @@ constexpr int FE_HROWS = FE_TH + 6;    // row-sum rows: image y0-3 .. y0+TH+2
 constexpr int FE_THREADS = 512;
 constexpr int FE_WAVES = FE_THREADS / 64;
 constexpr int FE_HALO_PIX = 2 * (FE_TW + 2) + 2 * FE_TH;             // 1-px rim around the tile
-constexpr int FE_RIM_PER_WAVE = (FE_HALO_PIX + FE_WAVES - 1) / FE_WAVES;
-constexpr int FE_WQ = FE_TW * FE_TH / FE_WAVES + FE_RIM_PER_WAVE;     // queue entries one wave can produce
+constexpr int FE_QCAP = FE_TW * FE_TH + FE_HALO_PIX;                  // queue entries a tile can produce
 static_assert(FE_TW == kTileW && FE_TH == kTileH, "candidate lists are indexed by this tile grid");
-static_assert(FE_THREADS == FE_TW / 4 * FE_TH && FE_RIM_PER_WAVE <= 64, "one quad per thread, rim fits a wave");
+static_assert(FE_THREADS == FE_TW / 4 * FE_TH && FE_HALO_PIX <= FE_THREADS, "one quad and one rim pixel per thread");
 
 // FAST-9/16 score of one pixel from its 16 ring values p[] and centre v:
 //   A = max over the 16 arcs of 9 of min(v - p) = v - min_arcs(max_arc p)
@@ -285,18 +284,18 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
 // One block = one 128x16 tile of one frame:
 //   0. the tile plus a 4-px apron is staged in LDS as 8-bit gray (BGR/BGRA are
 //      converted on the way in; 16-B vector loads, all issued before first use);
-//   1. per wave, without block-level synchronisation: cheap FAST pre-test of
-//      the wave's two tile rows and its share of the 1-px rim in packed 16-bit
-//      arithmetic, survivors compacted into the wave's own LDS queue (ballot +
-//      lane prefix), full FAST-9/16 score of the queued pixels into the LDS
-//      score tile.  The Gaussian's row sums (4-byte dot products, two rows per
-//      task) are computed in the same barrier interval;
-//   2. 3x3 strict non-max suppression (cv::FAST, nonmaxSuppression = true) of
-//      the wave's queued corners; survivors go straight to the tile's slot list
-//      in global memory as keys ((255-score) << 24) | raster index (slots from
-//      an LDS counter; the wave that finishes last stores the tile's count --
-//      no global atomics, no zero-initialised counters).  The Gaussian's column
-//      pass (2-element dot products over row pairs) runs in the same interval.
+//   1. cheap FAST pre-test on the tile and its 1-px rim in packed 16-bit
+//      arithmetic; survivors (about 8 % of the pixels) are compacted into one
+//      LDS queue (wave ballot + one LDS atomic per wave);
+//   2. the queue is processed densely by the first waves: full FAST-9/16 score
+//      into the LDS score tile; the other waves compute the Gaussian's row sums
+//      meanwhile (4-byte dot products, two rows per task);
+//   3. 3x3 strict non-max suppression (cv::FAST, nonmaxSuppression = true) of
+//      the queued corners; survivors go straight to the tile's slot list in
+//      global memory as keys ((255-score) << 24) | raster index (slots from an
+//      LDS counter; the wave that finishes last stores the tile's count -- no
+//      global atomics, no zero-initialised counters).  The other waves run the
+//      Gaussian's column pass (2-element dot products over row pairs).
 // tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
 //
 // Tile order is XCD-aware: blocks b and b+8 share an XCD (and its L2), so XCD
@@ -314,8 +313,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint32_t s_hpair[FE_HPAIRS * FE_TW];  // row sums of rows (2p, 2p+1)
-    __shared__ uint16_t s_queue[FE_WAVES * FE_WQ];
-    __shared__ uint32_t s_ecount, s_done;
+    __shared__ uint16_t s_queue[FE_QCAP];
+    __shared__ uint32_t s_qcount, s_ecount, s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             if (tid + u * FE_THREADS < FE_TASKS)
                 fe_issue<CN>(pre[u], img, src_stride, width, height, tile, tid + u * FE_THREADS, aligned);
         for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
-        if (tid == 0) { s_ecount = 0; s_done = 0; }
+        if (tid == 0) { s_qcount = 0; s_ecount = 0; s_done = 0; }
         FE_STAMP(1);
 #pragma unroll
         for (int u = 0; u < FE_TPT; u++) {
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
     const int x = x0 + gx * 4, y = y0 + gy;  // image position of the first of them
     const bool want_fast = score.base != nullptr || cand != nullptr;
-    int qn = 0;  // entries in this wave's queue
+    int qn = 0;  // entries in the tile queue
 
     if (want_fast) {
         // ---- 1. pre-test: interior (four pixels per thread) ...
@@ -391,14 +390,13 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         }
         const bool pass0 = (r01 & 0xffffu) != 0 && (vm & 1u), pass1 = (r01 >> 16) != 0 && (vm & 2u);
         const bool pass2 = (r23 & 0xffffu) != 0 && (vm & 4u), pass3 = (r23 >> 16) != 0 && (vm & 8u);
-        // ... and this wave's share of the 1-px rim around the tile (one pixel per lane)
+        // ... and the 1-px rim around the tile (one pixel per thread of the first waves)
         int hr = -1, hc = 0;
-        const int rim = wave * FE_RIM_PER_WAVE + lane;
-        if (lane < FE_RIM_PER_WAVE && rim < FE_HALO_PIX) {
-            if (rim < FE_TW + 2) { hr = 3; hc = 3 + rim; }
-            else if (rim < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + rim - (FE_TW + 2); }
-            else if (rim < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + rim - 2 * (FE_TW + 2); hc = 3; }
-            else { hr = 4 + rim - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
+        if (tid < FE_HALO_PIX) {
+            if (tid < FE_TW + 2) { hr = 3; hc = 3 + tid; }
+            else if (tid < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + tid - (FE_TW + 2); }
+            else if (tid < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + tid - 2 * (FE_TW + 2); hc = 3; }
+            else { hr = 4 + tid - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
             const int ix = x0 - 4 + hc, iy = y0 - 4 + hr;
             bool ok = ix >= 3 && ix < width - 3 && iy >= 3 && iy < height - 3;
             if (ok) {
@@ -407,29 +405,36 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             }
             if (!ok) hr = -1;
         }
-        // compact the survivors into this wave's queue
-        uint16_t *wq = s_queue + wave * FE_WQ;
+        // queue the survivors: one LDS atomic per wave
         {
             uint64_t m[5];
             m[0] = __ballot(pass0); m[1] = __ballot(pass1); m[2] = __ballot(pass2); m[3] = __ballot(pass3);
             m[4] = __ballot(hr >= 0);
-            const uint64_t lt = (1ull << lane) - 1ull;
-            const bool pass[4] = {pass0, pass1, pass2, pass3};
-            uint32_t base = 0;
+            uint32_t total = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (pass[i]) wq[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
-                base += (uint32_t)__popcll(m[i]);
+            for (int i = 0; i < 5; i++) total += (uint32_t)__popcll(m[i]);
+            if (total) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_qcount, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint64_t lt = (1ull << lane) - 1ull;
+                const bool pass[4] = {pass0, pass1, pass2, pass3};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (pass[i]) s_queue[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
+                    base += (uint32_t)__popcll(m[i]);
+                }
+                if (hr >= 0) s_queue[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
             }
-            if (hr >= 0) wq[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
-            qn = (int)(base + (uint32_t)__popcll(m[4]));
         }
-        __builtin_amdgcn_wave_barrier();
         FE_STAMP(4);
+        __syncthreads();
+        FE_STAMP(5);
 
-        // full score of the wave's queued pixels
-        for (int e = lane; e < qn; e += 64) {
-            const int q = wq[e];
+        // ---- 2. full score of the queued pixels (the first waves)
+        qn = (int)s_qcount;
+        for (int e = tid; e < qn; e += FE_THREADS) {
+            const int q = s_queue[e];
             const int r = q >> 8, cc = q & 255;
             const uint8_t *p = &s_gray[r * FE_PITCH + cc];
             uint32_t ring[16];
@@ -443,10 +448,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         }
     }
 
-    FE_STAMP(5);
-    // ---- Gaussian, row pass: row sums of tile rows 1 .. 22, two rows per task
+    // ---- Gaussian, row pass: row sums of tile rows 1 .. 22, two rows per task, taken by the last
+    // threads of the block so that the waves without queue entries do it
     if (blur.base) {
-        for (int t = tid; t < FE_HPAIRS * 32; t += FE_THREADS) {
+        for (int t = FE_THREADS - 1 - tid; t < FE_HPAIRS * 32; t += FE_THREADS) {
             const int hp = t >> 5, tg = t & 31;
             const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 1) * FE_PITCH + tg * 4]);
             const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 2) * FE_PITCH + tg * 4]);
@@ -463,17 +468,16 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     __syncthreads();
     FE_STAMP(7);
 
-    // ---- 2. non-max suppression of this wave's corners (score row sr <-> tile row sr + 3), direct emission
+    // ---- 3. non-max suppression of the queued corners (score row sr <-> tile row sr + 3), direct emission
     if (cand) {
         const int tile_id = (y0 / FE_TH) * tiles_x + x0 / FE_TW;
         uint32_t *out = cand + ((size_t)f * tiles_x * tiles_y + tile_id) * kTileCap;
-        const uint16_t *wq = s_queue + wave * FE_WQ;
-        for (int e0 = 0; e0 < qn; e0 += 64) {
+        for (int e0 = wave * 64; e0 < qn; e0 += FE_THREADS) {
             const int e = e0 + lane;
             bool is_max = false;
             uint32_t key = 0;
             if (e < qn) {
-                const int q = wq[e];
+                const int q = s_queue[e];
                 const int r = q >> 8, cc = q & 255;
                 // rim pixels only feed their neighbours
                 if (r >= 4 && r < 4 + FE_TH && cc >= 4 && cc < 4 + FE_TW) {
@@ -503,8 +507,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(8);
 
     // ---- Gaussian, column pass: output rows (2m, 2m+1) from the row pairs m .. m+3
-    if (blur.base && tid < (FE_TH / 2) * 32) {
-        const int m = tid >> 5, tg = tid & 31;
+    if (blur.base && tid >= FE_THREADS - (FE_TH / 2) * 32) {  // the waves that had no corners to suppress
+        const int ct = FE_THREADS - 1 - tid;
+        const int m = ct >> 5, tg = ct & 31;
         uint4 P[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) P[k] = *reinterpret_cast<const uint4 *>(&s_hpair[(m + k) * FE_TW + tg * 4]);

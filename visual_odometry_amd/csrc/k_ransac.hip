@@ -31,6 +31,7 @@ constexpr int FR_MAX_ATTEMPTS = 10000;
 struct FrShared {
     double models[FR_CHUNK][3][9];
     double best[9];
+    double min_median;  // LMedS: smallest median error so far
     int nmodels[FR_CHUNK];
     int counts[FR_CHUNK][3];
     int start[FR_CHUNK];
@@ -298,14 +299,21 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
         pts[i] = make_float4(g[i].px, g[i].py, g[i].cx, g[i].cy);
         msk[i] = 0;
     }
-    if (n < 15) {  // OpenCV would run LMedS here; reported as "not found"
+    if (n < 8) {  // the reference does not call findFundamentalMat below 8 points
         if (tid == 0) { inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0; }
         return;
     }
+    // Below 15 points cv::findFundamentalMat(FM_RANSAC) runs the LMedS estimator
+    // instead: a fixed iteration count (45 % outliers assumed, at most 1000), the
+    // model with the smallest median error wins, the inlier threshold comes from
+    // that median.  Subset drawing and the 7-point solver are shared.
+    const bool lmeds = n < 15;
     if (tid == 0) {
         S.iter = 0;
-        S.niters = prm.max_iters > 1 ? prm.max_iters : 1;
+        S.niters = lmeds ? max(ransac_update_num_iters(prm.confidence, 0.45, 7, 1000), 3)
+                         : (prm.max_iters > 1 ? prm.max_iters : 1);
         S.max_good = 0; S.done = 0; S.failed = 0; S.attempts = 0; S.pos = 0;
+        S.min_median = DBL_MAX;
     }
     __syncthreads();
 
@@ -376,6 +384,17 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             if (m >= S.nmodels[h]) continue;
             double F[9];
             for (int i = 0; i < 9; i++) F[i] = S.models[h][m][i];
+            if (lmeds) {
+                // median = element n/2 of the sorted errors: the lane whose error has that rank
+                const float e = lane < n ? f_error(pts[lane], F) : 0.f;
+                int rank = 0;
+                for (int j = 0; j < n; j++) {
+                    const float ej = __shfl(e, j);
+                    rank += (ej < e) || (ej == e && j < lane);
+                }
+                if (lane < n && rank == n / 2) S.counts[h][m] = __float_as_int(e);
+                continue;
+            }
             int cnt = 0;
             for (int i = lane; i < n; i += kWave) cnt += (f_error(pts[i], F) <= thr2);
             for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
@@ -387,6 +406,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             for (int h = 0; h < nc; h++) {
                 const int nm = S.nmodels[h];
                 for (int m = 0; m < nm; m++) {
+                    if (lmeds) {
+                        const double median = (double)__int_as_float(S.counts[h][m]);
+                        if (median < S.min_median) {
+                            S.min_median = median;
+                            for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
+                        }
+                        continue;
+                    }
                     const int goodc = S.counts[h][m];
                     if (goodc > max(S.max_good, 6)) {
                         for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
@@ -405,7 +432,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
     }
 
     // final mask, then the motion filter with ordered compaction
-    const bool found = S.max_good > 0;
+    // a model exists: RANSAC accepted one / LMedS saw a finite median
+    const bool found = lmeds ? S.min_median < DBL_MAX : S.max_good > 0;
+    float thr_final = thr2;
+    if (lmeds && found) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(S.min_median);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        thr_final = (float)(sigma * sigma);
+    }
     if (tid == 0) S.scan_base = 0;
     __syncthreads();
     double F[9];
@@ -416,7 +450,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
         const int i = i0 + tid;
         bool inl = false, keep = false;
         if (i < n && found) {
-            inl = f_error(pts[i], F) <= thr2;
+            inl = f_error(pts[i], F) <= thr_final;
             msk[i] = (uint8_t)inl;
             const float dx = pts[i].z - pts[i].x, dy = pts[i].w - pts[i].y;
             keep = inl && sqrtf(dx * dx + dy * dy) < 100.0f;
@@ -442,7 +476,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
     if (tid == 0) {
         int tot = 0;
         for (int w = 0; w < FR_THREADS / kWave; w++) tot += S.wave_tot[w];
-        inf[0] = found ? 1 : 0;
+        inf[0] = (lmeds ? (found && tot >= 7) : found) ? 1 : 0;  // LMedS reports failure below 7 inliers
         inf[1] = S.iter;
         inf[2] = tot;
         inf[3] = S.scan_base;

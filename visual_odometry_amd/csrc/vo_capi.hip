@@ -459,9 +459,9 @@ int vo_find_fundamental_ransac(vo_ctx *c, const float *p1, const float *p2, int 
     if (!p1 || !p2 || !mask || n < 0 || n > c->cfg.max_features)
         return fail(c, VO_ERR_ARG, "vo_find_fundamental_ransac: bad arguments (n %d, limit %d)", n,
                     c->cfg.max_features);
-    if (n < 15)
+    if (n < 8)
         return fail(c, VO_ERR_UNSUPPORTED,
-                    "vo_find_fundamental_ransac: %d points (< 15) would take OpenCV's LMedS branch", n);
+                    "vo_find_fundamental_ransac: %d points; the reference calls it with 8 or more", n);
     HIP_TRY(c, hipSetDevice(c->device));
     if (threshold <= 0) threshold = 3;
     if (confidence < 2.220446049250313e-16 || confidence > 1 - 2.220446049250313e-16) confidence = 0.99;
