@@ -13,7 +13,7 @@ import dataclasses
 
 import numpy as np
 
-__all__ = ["Camera", "Scene", "make_sequence", "CONFIG_CAMERAS"]
+__all__ = ["Camera", "Scene", "make_sequence", "make_stereo_sequence", "CONFIG_CAMERAS"]
 
 
 @dataclasses.dataclass(frozen=True)
@@ -133,7 +133,7 @@ def _rot(rx, ry, rz):
 
 
 def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
-                  noise_sigma: float = 2.0, scene: Scene | None = None):
+                  noise_sigma: float = 2.0, scene: Scene | None = None, baseline_mm: float = 0.0):
     """Return dict with 'frames' (n,H,W,C uint8 BGR[A] or n,H,W gray when channels==1),
     'depth' (n,H,W float32 mm), 'poses' (list of (R, c)) and 'camera'."""
     scene = scene or Scene(seed)
@@ -141,7 +141,8 @@ def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
     frames, depths, poses = [], [], []
     for k in range(n_frames):
         R = _rot(np.deg2rad(0.10 * k), np.deg2rad(0.25 * k), np.deg2rad(0.12 * k))
-        c = np.array([14.0 * k, 4.0 * k, 30.0 * k])
+        # baseline_mm moves the camera centre along its own x axis (the right camera of a stereo rig)
+        c = np.array([14.0 * k, 4.0 * k, 30.0 * k]) + R.T @ np.array([baseline_mm, 0.0, 0.0])
         gray, depth = scene.render(cam, R, c)
         gray = gray + rng.normal(0.0, noise_sigma, gray.shape).astype(np.float32)
         g8 = np.clip(np.rint(gray), 0, 255).astype(np.uint8)
@@ -160,6 +161,14 @@ def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
         poses.append((R, c))
     return {"frames": np.stack(frames), "depth": np.stack(depths), "poses": poses,
             "camera": cam}
+
+
+def make_stereo_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4, baseline_mm: float = 120.0):
+    """Left and right sequences of a rectified stereo rig looking at the same scene."""
+    scene = Scene(seed)
+    left = make_sequence(cam, n_frames, seed, channels, scene=scene)
+    right = make_sequence(cam, n_frames, seed + 1, channels, scene=scene, baseline_mm=baseline_mm)
+    return left, right
 
 
 def relative_pose(pose_prev, pose_curr):
