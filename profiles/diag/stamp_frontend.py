@@ -58,3 +58,7 @@ print("PnP, RANSAC loop total (stamp 1 -> 4): median", np.median(t[:, 4] - t[:, 
 for i, n in enumerate(names):
     print(f"{n:36s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
 print(f"{'whole kernel':36s} median {np.median(t[:, 10] - t[:, 0]):9.0f}")
+q = pn[:, 11:15].astype(np.int64)
+for i, n in enumerate(["  EPnP: control points + barycentric", "  EPnP: 10x12 singular vectors (16 lanes)",
+                       "  EPnP: betas, Gauss-Newton, R|t (3 lanes)"]):
+    print(f"{n:44s} median {np.median(q[:, i + 1] - q[:, i]):9.0f} cycles")

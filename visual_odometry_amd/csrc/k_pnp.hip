@@ -23,7 +23,7 @@
 
 namespace vo {
 
-constexpr int PR_THREADS = 512;
+constexpr int PR_THREADS = 128;
 constexpr int PR_WAVES = PR_THREADS / kWave;
 constexpr int PR_GROUP = 16;                      // lanes per hypothesis
 constexpr int PR_CHUNK = PR_THREADS / PR_GROUP;   // hypotheses per round
@@ -199,6 +199,59 @@ __device__ __forceinline__ void lstsq6(const double *Ain, const double *bin, dou
 #pragma unroll
         for (int j = k + 1; j < N; j++) s -= A[k * N + j] * x[j];
         x[k] = s / A[k * N + k];
+    }
+}
+
+// lstsq6<5> on a 6 x 5 matrix whose columns >= ncols are zero: the Householder
+// steps of the zero columns are no-ops, so the first ncols unknowns come out
+// exactly as lstsq6<ncols> would give them; the others are set to 0.
+__device__ __forceinline__ void lstsq6_pad5(const double *Ain, const double *bin, double *x, int ncols)
+{
+    constexpr int M = 6, N = 5;
+    double A[M * N], b[M];
+#pragma unroll
+    for (int i = 0; i < M * N; i++) A[i] = Ain[i];
+#pragma unroll
+    for (int i = 0; i < M; i++) b[i] = bin[i];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double s = 0;
+#pragma unroll
+        for (int i = k; i < M; i++) s += A[i * N + k] * A[i * N + k];
+        const double nrm = sqrt(s);
+        if (nrm == 0) continue;
+        const double alpha = A[k * N + k] > 0 ? -nrm : nrm;
+        double v[M];
+#pragma unroll
+        for (int i = k; i < M; i++) v[i] = A[i * N + k];
+        v[k] -= alpha;
+        double vn = 0;
+#pragma unroll
+        for (int i = k; i < M; i++) vn += v[i] * v[i];
+        if (vn == 0) continue;
+        const double beta = 2.0 / vn;
+#pragma unroll
+        for (int j = k; j < N; j++) {
+            double dot = 0;
+#pragma unroll
+            for (int i = k; i < M; i++) dot += v[i] * A[i * N + j];
+            dot *= beta;
+#pragma unroll
+            for (int i = k; i < M; i++) A[i * N + j] -= dot * v[i];
+        }
+        double dot = 0;
+#pragma unroll
+        for (int i = k; i < M; i++) dot += v[i] * b[i];
+        dot *= beta;
+#pragma unroll
+        for (int i = k; i < M; i++) b[i] -= dot * v[i];
+    }
+#pragma unroll
+    for (int k = N - 1; k >= 0; k--) {
+        double s = b[k];
+#pragma unroll
+        for (int j = k + 1; j < N; j++) s -= A[k * N + j] * x[j];
+        x[k] = k < ncols ? s / A[k * N + k] : 0.0;
     }
 }
 
@@ -539,105 +592,72 @@ __device__ void epnp_gauss_newton(const double *L, const double *rho, double *be
     }
 }
 
-// the part of epnp::compute_pose after the SVD: vv = the four singular
-// vectors of smallest singular value, smallest first (12 doubles each)
-__device__ bool epnp5_finish(const Epnp5 &e, const double *vv, double *R, double *t)
+// epnp::compute_L_6x10 and compute_rho from the four singular vectors of
+// smallest singular value vv[0..3] (smallest first, 12 doubles each)
+__device__ void epnp5_L_rho(const Epnp5 &e, const double *vv, double *L, double *rho)
 {
-    double L[60], rho[6];
-    {
-        double dv[4][6][3];
+    double dv[4][6][3];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double *v = vv + 12 * i;
-            int a = 0, b = 1;
+    for (int i = 0; i < 4; i++) {
+        const double *v = vv + 12 * i;
+        int a = 0, b = 1;
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                dv[i][j][0] = v[3 * a] - v[3 * b];
-                dv[i][j][1] = v[3 * a + 1] - v[3 * b + 1];
-                dv[i][j][2] = v[3 * a + 2] - v[3 * b + 2];
-                b++;
-                if (b > 3) { a++; b = a + 1; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double *row = L + 10 * i;
-            row[0] = dot3(dv[0][i], dv[0][i]);
-            row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
-            row[2] = dot3(dv[1][i], dv[1][i]);
-            row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
-            row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
-            row[5] = dot3(dv[2][i], dv[2][i]);
-            row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
-            row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
-            row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
-            row[9] = dot3(dv[3][i], dv[3][i]);
-        }
-        rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]);
-        rho[2] = dist2(e.cws[0], e.cws[3]); rho[3] = dist2(e.cws[1], e.cws[2]);
-        rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
-    }
-    double best_rep = 0, Rc[9], tc[3], be[4];
-    {   // approximation 1: [B11 B12 B13 B14]
-        double l[24], b4[4];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            l[i * 4] = L[i * 10]; l[i * 4 + 1] = L[i * 10 + 1];
-            l[i * 4 + 2] = L[i * 10 + 3]; l[i * 4 + 3] = L[i * 10 + 6];
-        }
-        lstsq6<4>(l, rho, b4);
-        if (b4[0] < 0) { be[0] = sqrt(-b4[0]); be[1] = -b4[1] / be[0]; be[2] = -b4[2] / be[0]; be[3] = -b4[3] / be[0]; }
-        else { be[0] = sqrt(b4[0]); be[1] = b4[1] / be[0]; be[2] = b4[2] / be[0]; be[3] = b4[3] / be[0]; }
-        epnp_gauss_newton(L, rho, be);
-        best_rep = epnp_R_and_t(e, vv, be, R, t);
-    }
-    {   // approximation 2: [B11 B12 B22]
-        double l[18], b3[3];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { l[i * 3] = L[i * 10]; l[i * 3 + 1] = L[i * 10 + 1]; l[i * 3 + 2] = L[i * 10 + 2]; }
-        lstsq6<3>(l, rho, b3);
-        if (b3[0] < 0) { be[0] = sqrt(-b3[0]); be[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-        else { be[0] = sqrt(b3[0]); be[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-        if (b3[1] < 0) be[0] = -be[0];
-        be[2] = 0.0; be[3] = 0.0;
-        epnp_gauss_newton(L, rho, be);
-        const double rep = epnp_R_and_t(e, vv, be, Rc, tc);
-        if (rep < best_rep) {
-            best_rep = rep;
-#pragma unroll
-            for (int i = 0; i < 9; i++) R[i] = Rc[i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) t[i] = tc[i];
+        for (int j = 0; j < 6; j++) {
+            dv[i][j][0] = v[3 * a] - v[3 * b];
+            dv[i][j][1] = v[3 * a + 1] - v[3 * b + 1];
+            dv[i][j][2] = v[3 * a + 2] - v[3 * b + 2];
+            b++;
+            if (b > 3) { a++; b = a + 1; }
         }
     }
-    {   // approximation 3: [B11 B12 B22 B13 B23]
-        double l[30], b5[5];
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 6; i++) {
+        double *row = L + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0 * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0 * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0 * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0 * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0 * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+    rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]);
+    rho[2] = dist2(e.cws[0], e.cws[3]); rho[3] = dist2(e.cws[1], e.cws[2]);
+    rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
+}
+
+// One of the three beta approximations of epnp::compute_pose (br = 0: [B11 B12
+// B13 B14], 1: [B11 B12 B22], 2: [B11 B12 B22 B13 B23]), refined by Gauss-Newton
+// and turned into R, t; returns the mean reprojection error.  The three are
+// independent, so three lanes of a hypothesis' group run one each.
+__device__ double epnp5_branch(const Epnp5 &e, const double *vv, const double *L, const double *rho, int br,
+                               double *R, double *t)
+{
+    double l[30], b5[5], be[4];
 #pragma unroll
-            for (int j = 0; j < 5; j++) l[i * 5 + j] = L[i * 10 + j];
-        lstsq6<5>(l, rho, b5);
+    for (int i = 0; i < 6; i++) {
+        l[i * 5] = L[i * 10];
+        l[i * 5 + 1] = L[i * 10 + 1];
+        l[i * 5 + 2] = br == 0 ? L[i * 10 + 3] : L[i * 10 + 2];
+        l[i * 5 + 3] = br == 0 ? L[i * 10 + 6] : (br == 2 ? L[i * 10 + 3] : 0.0);
+        l[i * 5 + 4] = br == 2 ? L[i * 10 + 4] : 0.0;
+    }
+    lstsq6_pad5(l, rho, b5, br == 0 ? 4 : (br == 1 ? 3 : 5));
+    if (br == 0) {
+        if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = -b5[1] / be[0]; be[2] = -b5[2] / be[0]; be[3] = -b5[3] / be[0]; }
+        else { be[0] = sqrt(b5[0]); be[1] = b5[1] / be[0]; be[2] = b5[2] / be[0]; be[3] = b5[3] / be[0]; }
+    } else {
         if (b5[0] < 0) { be[0] = sqrt(-b5[0]); be[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
         else { be[0] = sqrt(b5[0]); be[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
         if (b5[1] < 0) be[0] = -be[0];
-        be[2] = b5[3] / be[0];
+        be[2] = br == 2 ? b5[3] / be[0] : 0.0;
         be[3] = 0.0;
-        epnp_gauss_newton(L, rho, be);
-        const double rep = epnp_R_and_t(e, vv, be, Rc, tc);
-        if (rep < best_rep) {
-            best_rep = rep;
-#pragma unroll
-            for (int i = 0; i < 9; i++) R[i] = Rc[i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) t[i] = tc[i];
-        }
     }
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < 9; i++) ok = ok && isfinite(R[i]);
-#pragma unroll
-    for (int i = 0; i < 3; i++) ok = ok && isfinite(t[i]);
-    return ok;
+    epnp_gauss_newton(L, rho, be);
+    return epnp_R_and_t(e, vv, be, R, t);
 }
 
 // ---------------------------------------------------------------------
@@ -727,6 +747,22 @@ __device__ void block_reduce(PrShared &S, double (&v)[NV])
     __syncthreads();
 }
 
+#ifdef VO_FE_STAMPS
+// Diagnostic build only: cycle stamps of thread 0 of the first 256 blocks.
+__device__ unsigned long long g_pnp_stamps[256 * 16];
+#define PNP_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256)                                        \
+            g_pnp_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+extern "C" int vo_debug_pnp_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_stamps), sizeof(unsigned long long) * 256 * 16);
+}
+#else
+#define PNP_STAMP(i) do { } while (0)
+#endif
+
 // solve hypothesis `h` of the round (one per 16-lane group); all lanes call
 __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img, int h, bool active, double fx,
                                  double fy, double cx, double cy)
@@ -743,7 +779,9 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
         e.us[2 * i] = img[2 * idx[i]];
         e.us[2 * i + 1] = img[2 * idx[i] + 1];
     }
+    PNP_STAMP(11);
     bool ok = epnp5_prepare(e);
+    PNP_STAMP(12);
 
     // column gl of the 10 x 12 matrix M (epnp::fill_M): gl = 3k + c
     double g[10], v[12];
@@ -763,6 +801,7 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     double n2;
     int rank;
     group_svd12<10>(g, v, gl, &n2, &rank);
+    PNP_STAMP(13);
     // ranks 11, 10, 9, 8 are the four smallest singular values: vv[0..3]
     if (gl < 12 && rank >= 8) {
 #pragma unroll
@@ -770,38 +809,47 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    // the three beta approximations on lanes 0..2 of the group
+    double R[9], t[3];
+    double rep = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = 0;
+    t[0] = t[1] = t[2] = 0;
+    const bool run = active && ok;
+    if (gl < 3 && run) {
+        double vv[48], L[60], rho[6];
+#pragma unroll
+        for (int i = 0; i < 48; i++) vv[i] = S.vv[h][i / 12][i % 12];
+        epnp5_L_rho(e, vv, L, rho);
+        rep = epnp5_branch(e, vv, L, rho, gl, R, t);
+    }
+    PNP_STAMP(14);
+    // epnp::compute_pose keeps approximation 1 unless 2 reprojects better, then 3 unless it beats that
+    const int base = (threadIdx.x & 63) & ~(PR_GROUP - 1);
+    const double rep1 = __shfl(rep, base), rep2 = __shfl(rep, base + 1), rep3 = __shfl(rep, base + 2);
+    int win = 0;
+    double best_rep = rep1;
+    if (rep2 < best_rep) { win = 1; best_rep = rep2; }
+    if (rep3 < best_rep) win = 2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = __shfl(R[i], base + win);
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = __shfl(t[i], base + win);
     if (gl == 0) {
-        bool good = false;
-        if (active && ok) {
-            double vv[48], R[9], t[3], rv[3];
+        bool good = run;
 #pragma unroll
-            for (int i = 0; i < 48; i++) vv[i] = S.vv[h][i / 12][i % 12];
-            good = epnp5_finish(e, vv, R, t);
-            if (good) {
-                rodrigues_m2v(R, rv);
+        for (int i = 0; i < 9; i++) good = good && isfinite(R[i]);
 #pragma unroll
-                for (int i = 0; i < 3; i++) { S.model[h][i] = rv[i]; S.model[h][3 + i] = t[i]; }
-            }
+        for (int i = 0; i < 3; i++) good = good && isfinite(t[i]);
+        if (good) {
+            double rv[3];
+            rodrigues_m2v(R, rv);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { S.model[h][i] = rv[i]; S.model[h][3 + i] = t[i]; }
         }
         S.ok[h] = good ? 1 : 0;
     }
 }
-
-#ifdef VO_FE_STAMPS
-// Diagnostic build only: cycle stamps of thread 0 of the first 256 blocks.
-__device__ unsigned long long g_pnp_stamps[256 * 16];
-#define PNP_STAMP(i)                                                                     \
-    do {                                                                                 \
-        if (threadIdx.x == 0 && blockIdx.x < 256)                                        \
-            g_pnp_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();          \
-    } while (0)
-extern "C" int vo_debug_pnp_stamps(unsigned long long *out)
-{
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_stamps), sizeof(unsigned long long) * 256 * 16);
-}
-#else
-#define PNP_STAMP(i) do { } while (0)
-#endif
 
 // out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec
 __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__restrict__ valid,
