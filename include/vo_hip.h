@@ -167,6 +167,30 @@ int vo_detect_orb(vo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
 int vo_orb_get_level(vo_ctx *ctx, int frame, int level, int blurred, uint8_t *dst,
                      int dst_stride, int *w_out, int *h_out);
 
+/* cv::findEssentialMat(p1, p2, K, cv::RANSAC, prob, threshold, maxIters,
+ * mask) on pixel points (n x 2 float32): points are normalised with K, the
+ * threshold (pixels) is divided by (fx + fy) / 2, then the five-point RANSAC
+ * with Sampson error, cv::RNG seed 2^64-1.  E: 9 doubles row-major, Frobenius
+ * norm 1, p2^T K^-T E K^-1 p1 = 0.  No counterpart in the reference, which
+ * takes its pose from cv::solvePnPRansac (src/frame_processor.cpp:176-196):
+ * this is the monocular-pose estimator on top of it.  The five-point solutions
+ * agree with OpenCV's as a set (Nister's construction with a deterministic
+ * real-root finder), not bitwise. */
+int vo_find_essential_ransac(vo_ctx *ctx, const float *p1, const float *p2, int n,
+                             double fx, double fy, double cx, double cy, double prob,
+                             double threshold, int max_iters, uint8_t *mask, double *E,
+                             int *found, int *iters_run);
+
+/* Batched hypothesis generation and scoring from a fixed sample table:
+ * samples holds n_hyp x 5 point indices; for each sample the five-point
+ * solutions E (n_hyp x 10 x 9 doubles, unused entries 0), their number
+ * n_models (n_hyp) and per solution the number of the n points whose Sampson
+ * error is <= (threshold / ((fx + fy) / 2))^2 (counts, n_hyp x 10). */
+int vo_essential_hypotheses(vo_ctx *ctx, const float *p1, const float *p2, int n,
+                            double fx, double fy, double cx, double cy,
+                            const int32_t *samples, int n_hyp, double threshold,
+                            double *E, int32_t *n_models, int32_t *counts);
+
 /* ImageProcessor::processImage (reference src/image_processor.cpp:6-79,
  * include/visual_odometry/image_processor.hpp:8-38).  gray = BGR2GRAY of a
  * 3-channel frame or a copy of a 1-channel one.  With enhance != 0 also:

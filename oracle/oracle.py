@@ -66,6 +66,11 @@ def lib():
         _lib.ora_orb_quotas.argtypes = [C.c_int, C.c_float, C.c_int, C.c_void_p]
         _lib.ora_orb_detect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.ora_e_hypotheses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_find_essential_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -282,6 +287,49 @@ def find_fundamental_ransac(p1, p2, thr=3.0, conf=0.99, max_iters=1000):
     ok = lib().ora_find_fundamental_ransac(_p(p1), _p(p2), n, thr, conf, max_iters, _p(mask),
                                            _p(F), C.addressof(iters))
     return bool(ok), F.reshape(3, 3), mask[:n].copy(), iters.value
+
+
+def e5(q1, q2) -> np.ndarray:
+    """Five-point solutions for 5 normalised correspondences: (k, 3, 3)."""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    out = np.zeros((10, 9), np.float64)
+    n = lib().ora_e5(_p(q1), _p(q2), _p(out))
+    return out[:n].reshape(-1, 3, 3).copy()
+
+
+def e_error(q1, q2, E) -> np.ndarray:
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    err = np.zeros(len(q1), np.float32)
+    lib().ora_e_error(_p(q1), _p(q2), len(q1), _p(E), _p(err))
+    return err
+
+
+def e_hypotheses(q1, q2, idx, thr):
+    """Batched five-point hypotheses from an (H, 5) index table: E (H, 10, 9), n_models (H), counts (H, 10)."""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(-1, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 5)
+    H = len(idx)
+    E = np.zeros((H, 10, 9), np.float64)
+    nm = np.zeros(H, np.int32)
+    cnt = np.zeros((H, 10), np.int32)
+    lib().ora_e_hypotheses(_p(q1), _p(q2), len(q1), _p(idx), H, thr, _p(E), _p(nm), _p(cnt))
+    return E, nm, cnt
+
+
+def find_essential_ransac(p1, p2, fx, fy, cx, cy, prob=0.999, threshold=1.0, max_iters=1000):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = len(p1)
+    mask = np.zeros(max(n, 1), np.uint8)
+    E = np.zeros(9, np.float64)
+    iters = C.c_int(0)
+    ok = lib().ora_find_essential_ransac(_p(p1), _p(p2), n, fx, fy, cx, cy, prob, threshold, max_iters, _p(mask),
+                                         _p(E), C.addressof(iters))
+    return bool(ok), E.reshape(3, 3), mask[:n].copy(), iters.value
 
 
 def match_filter(knn, nt, qk, tk, ratio=0.7, knn_rev=None):

@@ -153,6 +153,20 @@ int ora_f7(const float *m1, const float *m2, double *Fout);
 void ora_f_error(const float *p1, const float *p2, int n, const double *F,
                  float *err);
 
+/* ---- essential matrix (monocular pose; not estimated by the reference) ---- */
+
+/* five-point solver on normalised points (5 x 2 doubles each): up to 10 E (9 doubles each, |E|_F = 1) */
+int ora_e5(const double *q1, const double *q2, double *Eout);
+/* Sampson error of n normalised correspondences */
+void ora_e_error(const double *q1, const double *q2, int n, const double *E, float *err);
+/* batched hypotheses from an index table (H x 5): solutions and inlier counts */
+void ora_e_hypotheses(const double *q1, const double *q2, int n, const int32_t *idx, int H, double thr, double *E,
+                      int32_t *n_models, int32_t *counts);
+/* cv::findEssentialMat(p1, p2, K, RANSAC, prob, threshold, maxIters, mask) on pixel points */
+int ora_find_essential_ransac(const float *p1, const float *p2, int n, double fx, double fy, double cx, double cy,
+                              double prob, double threshold, int max_iters, uint8_t *mask, double *E,
+                              int *iters_run);
+
 /* FeatureMatcher::match after kNN: ratio -> F-RANSAC mask -> 100 px motion
  * filter (reference src/feature_matcher.cpp:34-103).  Returns final count. */
 int ora_match_filter(const ora_knn2 *knn, int nq, int nt, const ora_kp *qk,

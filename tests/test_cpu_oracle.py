@@ -430,3 +430,59 @@ def test_orb_detect_structure(oracle, vga_seq):
     k1, d1 = oracle.orb_detect(g1, 1000)
     m, _, nr = oracle.match_filter(oracle.knn2(d, d1), len(k1), k, k1, 0.7)
     assert len(m) > 200
+
+
+def _rot(a, b, c):
+    ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+    return (np.array([[cc, -sc, 0], [sc, cc, 0], [0, 0, 1]]) @ np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]]) @
+            np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]]))
+
+
+def _essential(R, t):
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    return E / np.linalg.norm(E)
+
+
+def test_five_point_solver_exact_data(oracle):
+    """Every solution satisfies the epipolar and the cubic constraints; the true matrix is among them."""
+    rng = np.random.default_rng(0)
+    found = 0
+    for _ in range(100):
+        R = _rot(*rng.uniform(-0.15, 0.15, 3))
+        t = rng.normal(size=3); t /= np.linalg.norm(t)
+        X = np.c_[rng.uniform(-2, 2, 5), rng.uniform(-2, 2, 5), rng.uniform(4, 10, 5)]
+        X2 = X @ R.T + t
+        q1, q2 = X[:, :2] / X[:, 2:], X2[:, :2] / X2[:, 2:]
+        Es = oracle.e5(q1, q2)
+        assert 1 <= len(Es) <= 10 and len(Es) % 2 == 0
+        Et = _essential(R, t)
+        found += min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in Es) < 1e-7
+        h1, h2 = np.c_[q1, np.ones(5)], np.c_[q2, np.ones(5)]
+        for E in Es:
+            assert abs(np.linalg.norm(E) - 1) < 1e-12
+            assert np.abs(np.einsum("ni,ij,nj->n", h2, E, h1)).max() < 1e-9
+            assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-5 and abs(np.linalg.det(E)) < 1e-5
+            assert np.allclose(oracle.e_error(q1, q2, E), 0, atol=1e-16)
+    assert found >= 97
+
+
+def test_essential_ransac_labels_outliers(oracle):
+    rng = np.random.default_rng(5)
+    n, n_out, f = 500, 200, 700.0
+    R, t = _rot(0.03, -0.05, 0.02), np.array([0.8, 0.1, 0.2]) / np.linalg.norm([0.8, 0.1, 0.2])
+    X = np.c_[rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 12, n)]
+    X2 = X @ R.T + t
+    p1 = (f * X[:, :2] / X[:, 2:] + [640, 360] + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    p2 = (f * X2[:, :2] / X2[:, 2:] + [640, 360] + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    p2[:n_out] = rng.uniform(0, [1280, 720], (n_out, 2)).astype(np.float32)
+    ok, E, mask, iters = oracle.find_essential_ransac(p1, p2, f, f, 640, 360)
+    assert ok and 5 <= iters < 1000
+    assert mask[:n_out].sum() <= 3 and mask[n_out:].sum() > 0.6 * (n - n_out)
+    Et = _essential(R, t)
+    assert min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 0.05
+    ok2, E2, mask2, iters2 = oracle.find_essential_ransac(p1, p2, f, f, 640, 360)
+    assert np.array_equal(mask, mask2) and iters2 == iters  # fixed seed: deterministic
+    # exactly five points: the minimal solver once, every point an inlier of the accepted model
+    ok5, E5, m5, it5 = oracle.find_essential_ransac(p1[n_out:n_out + 5], p2[n_out:n_out + 5], f, f, 640, 360)
+    assert ok5 and m5.sum() == 5 and it5 == 1

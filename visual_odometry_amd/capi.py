@@ -74,6 +74,10 @@ EXPORTS = {
     "vo_detect_orb": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P,
                                 C.c_int, _P]),
     "vo_orb_get_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "vo_find_essential_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_int, _P, _P, _P, _P]),
+    "vo_essential_hypotheses": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _P,
+                                          C.c_int, C.c_double, _P, _P, _P]),
     "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, _P, _P, _P, _P, C.c_int]),
     "vo_match_features_ex": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P]),
@@ -199,6 +203,30 @@ class Context:
             self._h, _ptr(p1), _ptr(p2), n, threshold, confidence, max_iters, _ptr(mask), _ptr(F),
             C.addressof(found), C.addressof(iters)))
         return bool(found.value), F.reshape(3, 3), mask[:n].copy(), iters.value
+
+    def find_essential_ransac(self, p1, p2, fx, fy, cx, cy, prob=0.999, threshold=1.0, max_iters=1000):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        mask = np.zeros(max(n, 1), np.uint8)
+        E = np.zeros(9, np.float64)
+        found, iters = C.c_int(0), C.c_int(0)
+        self._check(self._lib.vo_find_essential_ransac(self._h, _ptr(p1), _ptr(p2), n, fx, fy, cx, cy, prob,
+                                                       threshold, max_iters, _ptr(mask), _ptr(E),
+                                                       C.addressof(found), C.addressof(iters)))
+        return bool(found.value), E.reshape(3, 3), mask[:n].copy(), iters.value
+
+    def essential_hypotheses(self, p1, p2, fx, fy, cx, cy, samples, threshold=1.0):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        samples = np.ascontiguousarray(samples, np.int32).reshape(-1, 5)
+        H = len(samples)
+        E = np.zeros((H, 10, 9), np.float64)
+        nm = np.zeros(H, np.int32)
+        cnt = np.zeros((H, 10), np.int32)
+        self._check(self._lib.vo_essential_hypotheses(self._h, _ptr(p1), _ptr(p2), len(p1), fx, fy, cx, cy,
+                                                      _ptr(samples), H, threshold, _ptr(E), _ptr(nm), _ptr(cnt)))
+        return E, nm, cnt
 
     def detect_orb(self, gray: np.ndarray, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20,
                    cap=None):

@@ -39,7 +39,105 @@ static bool is_device_ptr(const void *p)
     return a.type == hipMemoryTypeDevice;
 }
 
+int vo_ctx::ensure_essential(int n_points, int n_hyp)
+{
+    vo_ctx *c = this;
+    if (n_points > e_pts_cap) {
+        if (d_eq) (void)hipFree(d_eq);
+        if (d_emask) (void)hipFree(d_emask);
+        d_eq = nullptr; d_emask = nullptr; e_pts_cap = 0;
+        HIP_TRY(c, hipMalloc(&d_eq, sizeof(double) * 4 * (size_t)n_points));
+        HIP_TRY(c, hipMalloc(&d_emask, (size_t)n_points));
+        e_pts_cap = n_points;
+    }
+    if (!d_einfo) HIP_TRY(c, hipMalloc(&d_einfo, sizeof(int) * 4));
+    if (n_hyp > e_hyp_cap) {
+        for (void *p : {(void *)d_eE, (void *)d_eidx, (void *)d_enm, (void *)d_ecnt})
+            if (p) (void)hipFree(p);
+        d_eE = nullptr; d_eidx = nullptr; d_enm = nullptr; d_ecnt = nullptr; e_hyp_cap = 0;
+        HIP_TRY(c, hipMalloc(&d_eE, sizeof(double) * 90 * (size_t)n_hyp));
+        HIP_TRY(c, hipMalloc(&d_eidx, sizeof(int) * 5 * (size_t)n_hyp));
+        HIP_TRY(c, hipMalloc(&d_enm, sizeof(int) * (size_t)n_hyp));
+        HIP_TRY(c, hipMalloc(&d_ecnt, sizeof(int) * 10 * (size_t)n_hyp));
+        e_hyp_cap = n_hyp;
+    }
+    return VO_OK;
+}
+
+// pixel points -> normalised (x1, y1, x2, y2) quadruples on the device
+static int upload_normalised(vo_ctx *c, const float *p1, const float *p2, int n, double fx, double fy, double cx,
+                             double cy)
+{
+    std::vector<float> a(2 * (size_t)n), b(2 * (size_t)n);
+    HIP_TRY(c, hipMemcpy(a.data(), p1, sizeof(float) * 2 * n, hipMemcpyDefault));
+    HIP_TRY(c, hipMemcpy(b.data(), p2, sizeof(float) * 2 * n, hipMemcpyDefault));
+    std::vector<double> q(4 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        q[4 * i] = ((double)a[2 * i] - cx) / fx; q[4 * i + 1] = ((double)a[2 * i + 1] - cy) / fy;
+        q[4 * i + 2] = ((double)b[2 * i] - cx) / fx; q[4 * i + 3] = ((double)b[2 * i + 1] - cy) / fy;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_eq, q.data(), sizeof(double) * 4 * n, hipMemcpyHostToDevice));
+    return VO_OK;
+}
+
 extern "C" {
+
+int vo_find_essential_ransac(vo_ctx *c, const float *p1, const float *p2, int n, double fx, double fy, double cx,
+                             double cy, double prob, double threshold, int max_iters, uint8_t *mask, double *E,
+                             int *found, int *iters_run)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!p1 || !p2 || !mask || n < 0 || n > 65535 || !(fx > 0 && fy > 0) || !(threshold > 0) || !(prob > 0 && prob < 1))
+        return bfail(c, VO_ERR_ARG, "vo_find_essential_ransac: bad arguments (n %d)", n);
+    if (found) *found = 0;
+    if (iters_run) *iters_run = 0;
+    if (n < 5) {  // OpenCV asserts on fewer than five points
+        if (n > 0) memset(mask, 0, (size_t)n);
+        return VO_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = c->ensure_essential(n, 1);
+    if (rc) return rc;
+    if ((rc = upload_normalised(c, p1, p2, n, fx, fy, cx, cy))) return rc;
+    const double thr = threshold / ((fx + fy) / 2);
+    launch_e_ransac(c->d_eq, n, c->d_rng, c->rng_len, prob, (float)(thr * thr), max_iters, c->d_emask, c->d_eE,
+                    c->d_einfo, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_find_essential_ransac: %s", hipGetErrorString(e));
+    int info[4];
+    HIP_TRY(c, hipMemcpy(info, c->d_einfo, sizeof(int) * 3, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(mask, c->d_emask, (size_t)n, hipMemcpyDefault));
+    if (E) HIP_TRY(c, hipMemcpy(E, c->d_eE, sizeof(double) * 9, hipMemcpyDefault));
+    if (found) *found = info[0];
+    if (iters_run) *iters_run = info[1];
+    return VO_OK;
+}
+
+int vo_essential_hypotheses(vo_ctx *c, const float *p1, const float *p2, int n, double fx, double fy, double cx,
+                            double cy, const int32_t *samples, int n_hyp, double threshold, double *E,
+                            int32_t *n_models, int32_t *counts)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!p1 || !p2 || !samples || !E || !n_models || !counts || n < 5 || n_hyp < 1 || !(fx > 0 && fy > 0) ||
+        !(threshold > 0))
+        return bfail(c, VO_ERR_ARG, "vo_essential_hypotheses: bad arguments (n %d, hypotheses %d)", n, n_hyp);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = c->ensure_essential(n, n_hyp);
+    if (rc) return rc;
+    if ((rc = upload_normalised(c, p1, p2, n, fx, fy, cx, cy))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_eidx, samples, sizeof(int) * 5 * (size_t)n_hyp, hipMemcpyDefault));
+    HIP_TRY(c, hipMemsetAsync(c->d_eE, 0, sizeof(double) * 90 * (size_t)n_hyp, c->stream));
+    const double thr = threshold / ((fx + fy) / 2);
+    launch_e_hypotheses(c->d_eq, n, c->d_eidx, n_hyp, c->d_eE, c->d_enm, (float)(thr * thr), c->d_ecnt, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_essential_hypotheses: %s", hipGetErrorString(e));
+    HIP_TRY(c, hipMemcpy(E, c->d_eE, sizeof(double) * 90 * (size_t)n_hyp, hipMemcpyDefault));
+    HIP_TRY(c, hipMemcpy(n_models, c->d_enm, sizeof(int) * (size_t)n_hyp, hipMemcpyDefault));
+    HIP_TRY(c, hipMemcpy(counts, c->d_ecnt, sizeof(int) * 10 * (size_t)n_hyp, hipMemcpyDefault));
+    return VO_OK;
+}
 
 int vo_solve_pnp_ransac(vo_ctx *c, const float *obj, const float *img, int n, double fx, double fy, double cx,
                         double cy, int iters, double thr, double conf, double *rvec, double *tvec,

@@ -55,6 +55,13 @@ struct vo_ctx {
     uint32_t *d_orb_tab = nullptr;  // resize tables of all levels
     size_t orb_tab_cap = 0;
 
+    // essential-matrix operators (allocated on first use)
+    double *d_eq = nullptr, *d_eE = nullptr;
+    int *d_eidx = nullptr, *d_enm = nullptr, *d_ecnt = nullptr, *d_einfo = nullptr;
+    uint8_t *d_emask = nullptr;
+    int e_pts_cap = 0, e_hyp_cap = 0;
+    int ensure_essential(int n_points, int n_hyp);
+
     // pose stage
     float *d_depth = nullptr;  // staging for depth handed over from the host
     int *d_ages = nullptr;     // track ages, one row per feature slot

@@ -147,6 +147,15 @@ void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride,
                      int pairs, hipStream_t s);
 
 
+// Essential matrix.  q: n x (x1, y1, x2, y2) normalised points (doubles).
+// Hypotheses from an index table idx (H x 5): E (H x 10 x 9, unit Frobenius
+// norm), n_models (H), counts (H x 10) = points with Sampson error <= thr2.
+void launch_e_hypotheses(const double *q, int n, const int *idx, int H, double *E, int *n_models, float thr2,
+                         int *counts, hipStream_t s);
+// cv::findEssentialMat's RANSAC on one point set; info = {found, iters_run, n_inliers}
+void launch_e_ransac(const double *q, int n, const uint32_t *rng_raw, int rng_len, double prob, float thr2,
+                     int max_iters, uint8_t *mask, double *E, int *info, hipStream_t s);
+
 // ---- pose stage -------------------------------------------------------------
 
 // Per stream, sequentially over its frames: track ages of the current
