@@ -739,29 +739,46 @@ void launch_select(const uint32_t *cand, const uint32_t *tile_count, uint32_t *f
 // 32 lanes per keypoint, one descriptor byte (8 tests) per lane.
 // cv::ORB::compute's computeOrbDescriptors with WTA_K = 2
 // (reference src/feature_detector.cpp:73).  The pattern holds the 512 sample
-// offsets already rotated by the (constant) keypoint angle and rounded.
+// offsets already rotated by the (constant) keypoint angle and rounded; they
+// stay within +-13 px, so the 27 x 27 patch of each keypoint is first staged
+// in LDS with dword loads (a keypoint's 32 lanes fetch four rows per
+// instruction) and the 512 samples are LDS byte reads instead of 512 scattered
+// global ones.
+constexpr int BR_R = 13;
+constexpr int BR_PWD = (2 * BR_R + 1 + 3 + 3) / 4;  // dwords per staged row (any alignment of the first column)
 __global__ __launch_bounds__(256) void k_brief(PlaneBatch blur, const vo_kp *__restrict__ kps, int kp_stride,
                                                const int *__restrict__ nkp,
                                                const int8_t *__restrict__ pattern,
                                                uint8_t *__restrict__ desc)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BR_R + 1) * BR_PWD];
     reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
-    __syncthreads();
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int g = threadIdx.x >> 5, k = blockIdx.x * 8 + g;
     const int byte = threadIdx.x & 31;
-    if (k >= nkp[f]) return;
-    const vo_kp kp = kps[(size_t)f * kp_stride + k];
-    const int pitch = blur.pitch;
-    const uint8_t *center = blur.base + f * blur.plane_stride + (size_t)__float2int_rn(kp.y) * pitch +
-                            __float2int_rn(kp.x);
+    const bool live = k < nkp[f];
+    int col0 = 0;
+    if (live) {
+        const vo_kp kp = kps[(size_t)f * kp_stride + k];
+        const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+        const int x_al = (cx - BR_R) & ~3;  // keypoints are >= 31 px inside the image: never negative
+        col0 = cx - x_al;
+        const uint8_t *src = blur.base + f * blur.plane_stride + (size_t)(cy - BR_R) * blur.pitch + x_al;
+        for (int i = byte; i < (2 * BR_R + 1) * BR_PWD; i += 32) {
+            const int r = i / BR_PWD, c = i - r * BR_PWD;
+            s_patch[g][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * blur.pitch + 4 * c);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BR_R * (BR_PWD * 4) + col0;
     const int8_t *p = s_pat + byte * 32;
     uint32_t val = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const int t0 = center[p[4 * b + 1] * pitch + p[4 * b + 0]];
-        const int t1 = center[p[4 * b + 3] * pitch + p[4 * b + 2]];
+        const int t0 = center[p[4 * b + 1] * (BR_PWD * 4) + p[4 * b + 0]];
+        const int t1 = center[p[4 * b + 3] * (BR_PWD * 4) + p[4 * b + 2]];
         val |= (uint32_t)(t0 < t1) << b;
     }
     desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;

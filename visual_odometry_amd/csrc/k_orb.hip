@@ -400,6 +400,10 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
 // 32 lanes per keypoint, one descriptor byte per lane: computeOrbDescriptors()
 // with WTA_K = 2 on the blurred level image of the keypoint's octave, the
 // 31x31 pattern rotated by the keypoint angle per sample (float32, cvRound).
+// The pattern's largest radius is 18.4 px, so every rotated sample lies within
+// +-18 px: the 37 x 37 patch is staged in LDS with dword loads first.
+constexpr int BS_R = 18;
+constexpr int BS_PWD = (2 * BS_R + 1 + 3 + 3) / 4;
 __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8_t *__restrict__ pyr_blur,
                                                       const vo_kp *__restrict__ kps, int kp_stride,
                                                       const int *__restrict__ nkp,
@@ -407,21 +411,34 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
                                                       uint8_t *__restrict__ desc)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
     reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
-    __syncthreads();
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int g = threadIdx.x >> 5, k = blockIdx.x * 8 + g;
     const int byte = threadIdx.x & 31;
-    if (k >= nkp[f]) return;
-    const vo_kp kp = kps[(size_t)f * kp_stride + k];
-    const OrbLevel L = plan.lv[kp.octave];
-    const float inv = 1.f / L.scale;
-    float angle = kp.angle;
-    angle *= (float)(3.14159265358979323846 / 180.f);
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
-    const int pitch = L.pitch;
-    const uint8_t *center = pyr_blur + (size_t)f * plan.frame_bytes + L.off +
-                            (size_t)__float2int_rn(kp.y * inv) * pitch + __float2int_rn(kp.x * inv);
+    const bool live = k < nkp[f];
+    int col0 = 0;
+    float a = 1.f, b = 0.f;
+    if (live) {
+        const vo_kp kp = kps[(size_t)f * kp_stride + k];
+        const OrbLevel L = plan.lv[kp.octave];
+        const float inv = 1.f / L.scale;
+        float angle = kp.angle;
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        a = (float)cos((double)angle);
+        b = (float)sin((double)angle);
+        const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
+        const int x_al = (cx - BS_R) & ~3;  // keypoints are >= 31 px inside their level: never negative
+        col0 = cx - x_al;
+        const uint8_t *src = pyr_blur + (size_t)f * plan.frame_bytes + L.off + (size_t)(cy - BS_R) * L.pitch + x_al;
+        for (int i = byte; i < (2 * BS_R + 1) * BS_PWD; i += 32) {
+            const int r = i / BS_PWD, c = i - r * BS_PWD;
+            s_patch[g][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0;
     const int8_t *p = s_pat + byte * 32;
     uint32_t val = 0;
 #pragma unroll
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
         const float x1 = (float)p[4 * t + 2], y1 = (float)p[4 * t + 3];
         const int ix0 = __float2int_rn(x0 * a - y0 * b), iy0 = __float2int_rn(x0 * b + y0 * a);
         const int ix1 = __float2int_rn(x1 * a - y1 * b), iy1 = __float2int_rn(x1 * b + y1 * a);
-        const int t0 = center[iy0 * pitch + ix0];
-        const int t1 = center[iy1 * pitch + ix1];
+        const int t0 = center[iy0 * (BS_PWD * 4) + ix0];
+        const int t1 = center[iy1 * (BS_PWD * 4) + ix1];
         val |= (uint32_t)(t0 < t1) << t;
     }
     desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
