@@ -633,14 +633,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
         __syncthreads();
         for (int i = tid; i < M; i += SEL_THREADS) atomicAdd(&s_hist[c[i] >> 24], 1u);
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, b = 0;
-            for (; b < 256; b++) {
-                if (cum + (int)s_hist[b] >= max_features) break;
-                cum += (int)s_hist[b];
+        {
+            // the score class at which the running count reaches max_features
+            const uint32_t hv = tid < 256 ? s_hist[tid] : 0u;
+            const uint32_t inc = block_scan_inclusive<SEL_THREADS>(hv, s_scan);
+            const uint32_t target = (uint32_t)max_features;
+            if (tid < 256 && inc >= target && inc - hv < target) {
+                s_cut_bin = tid;
+                s_need = (int)(target - (inc - hv));  // >= 1 keys to take from the tied class
             }
-            s_cut_bin = b;
-            s_need = max_features - cum;  // >= 1 keys to take from the tied class
         }
         __syncthreads();
         const uint32_t cb = (uint32_t)s_cut_bin;
@@ -649,13 +650,23 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
             if ((k >> 24) == cb) atomicAdd(&s_rows[(k & 0xffffffu) / (uint32_t)width], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, r = 0;
-            for (; r < height; r++) {
-                cum += (int)s_rows[r];
-                if (cum >= s_need) break;
+        {
+            // the image row at which the tied class has supplied the keys still needed (4 rows per thread)
+            static_assert(kMaxDim == 4 * SEL_THREADS, "four row bins per thread");
+            uint32_t rv[4], sum4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { rv[j] = s_rows[4 * tid + j]; sum4 += rv[j]; }
+            const uint32_t inc = block_scan_inclusive<SEL_THREADS>(sum4, s_scan);
+            const uint32_t need = (uint32_t)s_need;
+            uint32_t cum = inc - sum4;
+            if (cum < need && inc >= need) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool before = cum < need;
+                    cum += rv[j];
+                    if (before && cum >= need) s_cut_row = 4 * tid + j;
+                }
             }
-            s_cut_row = r;
         }
     }
     __syncthreads();
@@ -701,15 +712,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
         const int yy = raster / (uint32_t)width, xx = raster - yy * width;
         cnt += (size_ok && xx >= border && xx < width - border && yy >= border && yy < height - border);
     }
-    s_scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < SEL_THREADS; off <<= 1) {
-        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    int out = (int)s_scan[tid] - cnt;
+    const uint32_t inc_cnt = block_scan_inclusive<SEL_THREADS>((uint32_t)cnt, s_scan);
+    int out = (int)inc_cnt - cnt;
     vo_kp *o = kps + (size_t)f * kp_stride;
     for (int i = begin; i < end; i++) {
         const uint32_t key = s_keys[i];
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
             o[out++] = kp;
         }
     }
-    if (tid == SEL_THREADS - 1) nkp[f] = (int)s_scan[tid];
+    if (tid == SEL_THREADS - 1) nkp[f] = (int)inc_cnt;
 }
 
 void launch_select(const uint32_t *cand, const uint32_t *tile_count, uint32_t *flat, int width, int height,

@@ -198,14 +198,16 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
             if (in_border(k & 0xffffffu)) atomicAdd(&s_hist[k >> 24], 1u);
         }
     __syncthreads();
-    if (tid == 0 && size_ok) {
-        // bins are 255 - score: walk from the best score down until 2*quota corners are covered
-        int cum = 0, b = 0;
-        for (; b < 256; b++) {
-            cum += (int)s_hist[b];
-            if (cum >= 2 * quota) break;
+    {
+        // bins are 255 - score: the first bin at which the running count covers 2*quota corners;
+        // every bin <= cut survives (all of them when fewer than 2*quota exist)
+        const uint32_t hv = tid < 256 ? s_hist[tid] : 0u;
+        const uint32_t inc = block_scan_inclusive<OS_THREADS>(hv, s_scan);
+        const uint32_t target = 2u * (uint32_t)quota;
+        if (tid < 256 && size_ok) {
+            if (inc >= target && inc - hv < target) s_cut = tid;
+            else if (tid == 255 && inc < target) s_cut = 255;
         }
-        s_cut = min(b, 255);  // every bin <= cut survives (all of them when fewer than 2*quota exist)
     }
     __syncthreads();
 
@@ -245,14 +247,15 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
                 if ((k & hi_mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                int rem = s_remaining, d = 255;
-                for (; d > 0; d--) {
-                    if ((int)s_hist[d] >= rem) break;
-                    rem -= (int)s_hist[d];
+            {
+                // the digit d with sum(hist[j > d]) < rem <= sum(hist[j >= d]): thread t owns digit 255 - t
+                const uint32_t rem = (uint32_t)s_remaining;
+                const uint32_t hv = tid < 256 ? s_hist[255 - tid] : 0u;
+                const uint32_t inc = block_scan_inclusive<OS_THREADS>(hv, s_scan);
+                if (tid < 256 && inc >= rem && inc - hv < rem) {
+                    s_remaining = (int)(rem - (inc - hv));
+                    s_prefix = prefix | ((uint32_t)(255 - tid) << shift);
                 }
-                s_remaining = rem;
-                s_prefix = prefix | ((uint32_t)d << shift);
             }
             __syncthreads();
         }

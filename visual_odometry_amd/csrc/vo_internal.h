@@ -190,9 +190,30 @@ void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const 
                     hipStream_t s);
 
 #ifdef __HIPCC__
+// Inclusive prefix sum of one value per thread over the whole block (THREADS a
+// multiple of 64, at most 1024): wave scans by shuffles, then the waves'
+// totals.  s_part: LDS scratch for THREADS / 64 words.  Every thread of the
+// block must call it (two barriers inside).
+template <int THREADS>
+__device__ inline uint32_t block_scan_inclusive(uint32_t v, uint32_t *s_part)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) s_part[wave] = x;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) x += s_part[w];
+    __syncthreads();
+    return x;
+}
+
 // One block gathers the per-tile corner lists of a frame (tile t holds
 // count[t] keys at cand[t*kTileCap ...]) into the contiguous list `flat` and
-// returns its length.  s_off: LDS scratch for ntiles words, s_scan: THREADS
+// returns its length.  s_off: LDS scratch for ntiles words, s_scan: THREADS / 64
 // words.  Ends with a barrier: every thread may read flat[] afterwards.
 template <int THREADS>
 __device__ inline int flatten_tile_lists(const uint32_t *__restrict__ cand, const uint32_t *__restrict__ count,
@@ -207,21 +228,14 @@ __device__ inline int flatten_tile_lists(const uint32_t *__restrict__ cand, cons
     const int t0 = min(tid * per, ntiles), t1 = min(t0 + per, ntiles);
     uint32_t sum = 0;
     for (int t = t0; t < t1; t++) sum += s_off[t];
-    s_scan[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < THREADS; off <<= 1) {
-        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_scan[tid] - sum;
+    const uint32_t inc = block_scan_inclusive<THREADS>(sum, s_scan);
+    uint32_t run = inc - sum;
     for (int t = t0; t < t1; t++) {
         const uint32_t n = s_off[t];
         s_off[t] = run;
         run += n;
     }
-    if (tid == THREADS - 1) s_total = s_scan[tid];
+    if (tid == THREADS - 1) s_total = inc;
     __syncthreads();
     const uint32_t total = s_total;
     const int lane = tid & 63;
