@@ -331,19 +331,20 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 constexpr int OF_THREADS = 256;
 
-// One wave per output keypoint: concatenates the levels' survivors (level by
+// 32 lanes per output keypoint: concatenates the levels' survivors (level by
 // level), computes the intensity-centroid angle over the radius-15 disc of
 // the keypoint's level image (ICAngles()) and writes the cv::KeyPoint with
 // pt scaled to level-0 coordinates, size = 31 * scale, octave = level.
-// Lanes 0..30 / 32..62 own the 31 columns u = -15..15 of the even / odd rows.
+// Lanes 0..30 of the group own the 31 columns u = -15..15; the 31 row loads of
+// a lane are all issued before the first use.
 __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const uint8_t *__restrict__ pyr,
                                                           const uint32_t *__restrict__ lvl_ras,
                                                           const float *__restrict__ lvl_resp,
                                                           const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
                                                           int kp_stride, int *__restrict__ nkp)
 {
-    const int f = blockIdx.y, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (OF_THREADS / 64) + (threadIdx.x >> 6);
+    const int f = blockIdx.y, gl = threadIdx.x & 31;
+    const int i = blockIdx.x * (OF_THREADS / 32) + (threadIdx.x >> 5);
     int level = -1, j = 0, total = 0;
     for (int l = 0; l < plan.nlevels; l++) {
         const int n = lvl_n[f * plan.nlevels + l];
@@ -352,45 +353,39 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
     }
     total = min(total, kp_stride);
     if (blockIdx.x == 0 && threadIdx.x == 0) nkp[f] = total;
-    if (level < 0 || i >= total) return;
+    const bool live = level >= 0 && i < total;
+    const int lv = live ? level : 0;
+    const int Lw = plan.lv[lv].w, Lpitch = plan.lv[lv].pitch;
+    const float Lscale = plan.lv[lv].scale;
+    const size_t Loff = plan.lv[lv].off;
+    const size_t o = ((size_t)f * plan.nlevels + lv) * kOrbLevelCap + (live ? j : 0);
+    const uint32_t ras = live ? lvl_ras[o] : (uint32_t)(15 * Lw + 15);
+    const int y = ras / (uint32_t)Lw, x = ras - y * Lw;
+    const uint8_t *center = pyr + (size_t)f * plan.frame_bytes + Loff + (size_t)y * Lpitch + x;
 
-    const OrbLevel L = plan.lv[level];
-    const size_t o = ((size_t)f * plan.nlevels + level) * kOrbLevelCap + j;
-    const uint32_t ras = lvl_ras[o];
-    const int y = ras / (uint32_t)L.w, x = ras - y * L.w;
-    const uint8_t *center = pyr + (size_t)f * plan.frame_bytes + L.off + (size_t)y * L.pitch + x;
-
-    // Row v = -15 + half + 2k for k = 0..15 (v = 16 does not exist: masked).  All 16 loads
-    // are issued before the first use; the disc test only gates the accumulation.
-    const int u = (lane & 31) - 15, half = lane >> 5;
-    const int au = abs(u);
+    const int u = min(gl - 15, 15);  // lane 31 of the group repeats column 15 and is masked below
+    const int au = gl == 31 ? 16 : abs(u);
+    int val[31];
+#pragma unroll
+    for (int k = 0; k < 31; k++) val[k] = center[(k - 15) * Lpitch + u];
     int m10 = 0, m01 = 0;
-    int val[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int v = min(-15 + half + 2 * k, 15);
-        val[k] = center[v * L.pitch + min(u, 15)];
+    for (int k = 0; k < 31; k++) {
+        const int v = k - 15;
+        const int xk = au <= kUmaxC(v < 0 ? -v : v) ? val[k] : 0;
+        m10 += u * xk;
+        m01 += v * xk;
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int v0 = -15 + 2 * k, v1 = -14 + 2 * k;  // compile-time rows of the two half-waves
-        const int d0 = kUmaxC(v0 < 0 ? -v0 : v0), d1 = v1 > 15 ? -1 : kUmaxC(v1 < 0 ? -v1 : v1);
-        const int d = half ? d1 : d0;
-        const int v = half ? v1 : v0;
-        const int x = au <= d ? val[k] : 0;
-        m10 += u * x;
-        m01 += v * x;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off > 0; off >>= 1) {
         m10 += __shfl_xor(m10, off);
         m01 += __shfl_xor(m01, off);
     }
-    if (lane == 0) {
+    if (live && gl == 0) {
         vo_kp kp;
-        kp.x = (float)x * L.scale;
-        kp.y = (float)y * L.scale;
-        kp.size = 31 * L.scale;
+        kp.x = (float)x * Lscale;
+        kp.y = (float)y * Lscale;
+        kp.size = 31 * Lscale;
         kp.angle = fast_atan2_deg((float)m01, (float)m10);
         kp.response = lvl_resp[o];
         kp.octave = level;
@@ -557,7 +552,7 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
                        const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s)
 {
-    dim3 grid((kp_stride + OF_THREADS / 64 - 1) / (OF_THREADS / 64), batch);
+    dim3 grid((kp_stride + OF_THREADS / 32 - 1) / (OF_THREADS / 32), batch);
     hipLaunchKernelGGL(k_orb_finish, grid, dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras, lvl_resp, lvl_n, kps,
                        kp_stride, nkp);
 }
