@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=16, help="independent camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="independent camera streams per GPU")
     ap.add_argument("--frames", type=int, default=16, help="consecutive frames per stream per step (even)")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--contexts", type=int, default=1,
