@@ -58,7 +58,8 @@ class Scene:
 
     MM_PER_TEXEL = 4.0
 
-    def __init__(self, seed: int, extent_mm=(16000.0, 10000.0), n_shapes: int = 900):
+    def __init__(self, seed: int, extent_mm=(16000.0, 10000.0), n_shapes: int = 900, relief: float = 1.0):
+        self.relief = relief  # scales the height variation of the surface (1.0: +-1150 mm around 3.5 m)
         rng = np.random.default_rng(seed)
         tw = int(extent_mm[0] / self.MM_PER_TEXEL)
         th = int(extent_mm[1] / self.MM_PER_TEXEL)
@@ -83,10 +84,9 @@ class Scene:
         self.extent = extent_mm
         self.seed = seed
 
-    @staticmethod
-    def surface(u, v):
-        return (3500.0 + 900.0 * np.sin(u / 1500.0) * np.cos(v / 1200.0)
-                + 250.0 * np.sin(u / 500.0 + v / 700.0))
+    def surface(self, u, v):
+        return 3500.0 + self.relief * (900.0 * np.sin(u / 1500.0) * np.cos(v / 1200.0)
+                                       + 250.0 * np.sin(u / 500.0 + v / 700.0))
 
     def sample(self, u, v):
         tx = (u + self.extent[0] / 2) / self.MM_PER_TEXEL
