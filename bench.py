@@ -38,12 +38,16 @@ def build_inputs(streams, frames, seed):
     from visual_odometry_amd import synth
     cam = synth.CONFIG_CAMERAS["hd720"]
     n_distinct = frames // 2 + 1
-    seq = synth.make_sequence(cam, n_distinct, seed=seed, channels=4)
+    # strong depth relief keeps the pose problem well posed (a nearly planar scene makes the DLT
+    # initialisation of the PnP refinement ambiguous)
+    seq = synth.make_sequence(cam, n_distinct, seed=seed, channels=4, scene=synth.Scene(seed, relief=2.0))
     order = pingpong(n_distinct)
     assert len(order) == frames
     f = np.stack([seq["frames"][i] for i in order])
     d = np.stack([seq["depth"][i] for i in order])
-    return cam, np.concatenate([f] * streams), np.concatenate([d] * streams)
+    # ground-truth T_prev_from_curr of every frame of a stream (frame 0 follows the last frame of the cycle)
+    truth = [synth.relative_pose(seq["poses"][order[k - 1]], seq["poses"][order[k]]) for k in range(frames)]
+    return cam, np.concatenate([f] * streams), np.concatenate([d] * streams), truth
 
 
 def cpu_baseline(cam, frames, depth, n_frames, max_features, orb_levels):
@@ -97,7 +101,7 @@ def main():
     S, F = args.streams // NC, args.frames   # streams per context
     Bc = S * F                               # frames per context per step
     B = Bc * NC                              # frames per step per GPU
-    cam, frames_h, depth_h = build_inputs(S, F, seed=2000 + rank)
+    cam, frames_h, depth_h, truth = build_inputs(S, F, seed=2000 + rank)
     H, W, C = cam.height, cam.width, 4
     K = (cam.fx, cam.fy, cam.cx, cam.cy)
     # every context owns its own copy of the input frames in HBM
@@ -206,6 +210,10 @@ def main():
             "mean_keypoints": n_kp, "mean_matches": float(res["n_matches"].mean()),
             "pose_success_rate": float(res["pnp_success"].mean()),
         }
+        # accuracy of the last step's poses against the rendered camera motion (T_prev_from_curr, mm)
+        t_err = [float(np.linalg.norm(res["tvec"][b] - truth[b % F][1])) for b in range(len(res)) if res["pnp_success"][b]]
+        out["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
+        out["ground_truth_step_mm"] = float(np.linalg.norm(truth[1][1]))
         if world == 1 and args.cpu_frames > 0:
             cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
