@@ -191,6 +191,20 @@ int vo_essential_hypotheses(vo_ctx *ctx, const float *p1, const float *p2, int n
                             const int32_t *samples, int n_hyp, double threshold,
                             double *E, int32_t *n_models, int32_t *counts);
 
+/* cv::recoverPose(E, p1, p2, K, R, t, mask) with distanceThresh as given (50
+ * in OpenCV's K overload): the monocular counterpart of the pose the reference
+ * takes from solvePnPRansac (src/frame_processor.cpp:176-196; the reference
+ * itself never decomposes an essential matrix).  The four candidates of
+ * cv::decomposeEssentialMat, every correspondence triangulated under each, the
+ * first candidate in the order (R1,t) (R2,t) (R1,-t) (R2,-t) with the most
+ * points in front of both cameras and nearer than distance_thresh wins.
+ * p1/p2: n x 2 float32 pixels; mask (n bytes) is ANDed into the votes when
+ * use_mask is non-zero and always receives the winner's 0/1 votes.  R: 3 x 3
+ * row-major, t: unit 3-vector, x2 ~ R x1 + t; *n_good = votes of the winner. */
+int vo_recover_pose(vo_ctx *ctx, const double *E, const float *p1, const float *p2, int n,
+                    double fx, double fy, double cx, double cy, double distance_thresh,
+                    int use_mask, uint8_t *mask, double *R, double *t, int *n_good);
+
 /* ImageProcessor::processImage (reference src/image_processor.cpp:6-79,
  * include/visual_odometry/image_processor.hpp:8-38).  gray = BGR2GRAY of a
  * 3-channel frame or a copy of a 1-channel one.  With enhance != 0 also:

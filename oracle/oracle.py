@@ -71,6 +71,9 @@ def lib():
         _lib.ora_find_essential_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.ora_recover_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -330,6 +333,28 @@ def find_essential_ransac(p1, p2, fx, fy, cx, cy, prob=0.999, threshold=1.0, max
     ok = lib().ora_find_essential_ransac(_p(p1), _p(p2), n, fx, fy, cx, cy, prob, threshold, max_iters, _p(mask),
                                          _p(E), C.addressof(iters))
     return bool(ok), E.reshape(3, 3), mask[:n].copy(), iters.value
+
+
+def decompose_essential(E):
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    R1, R2, t = np.zeros(9), np.zeros(9), np.zeros(3)
+    lib().ora_decompose_essential(_p(E), _p(R1), _p(R2), _p(t))
+    return R1.reshape(3, 3), R2.reshape(3, 3), t
+
+
+def recover_pose(E, p1, p2, fx, fy, cx, cy, mask=None, distance_thresh=50.0):
+    """cv::recoverPose: (votes, R, t, mask) with mask the winner's 0/1 votes."""
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = len(p1)
+    m = np.zeros(max(n, 1), np.uint8)
+    if mask is not None:
+        m[:n] = np.asarray(mask, np.uint8).reshape(-1)[:n]
+    R, t = np.zeros(9), np.zeros(3)
+    good = lib().ora_recover_pose(_p(E), _p(p1), _p(p2), n, fx, fy, cx, cy, distance_thresh,
+                                  int(mask is not None), _p(m), _p(R), _p(t))
+    return good, R.reshape(3, 3), t, m[:n].copy()
 
 
 def match_filter(knn, nt, qk, tk, ratio=0.7, knn_rev=None):

@@ -166,6 +166,10 @@ void ora_e_hypotheses(const double *q1, const double *q2, int n, const int32_t *
 int ora_find_essential_ransac(const float *p1, const float *p2, int n, double fx, double fy, double cx, double cy,
                               double prob, double threshold, int max_iters, uint8_t *mask, double *E,
                               int *iters_run);
+/* cv::decomposeEssentialMat and cv::recoverPose(E, p1, p2, K, R, t, mask) */
+void ora_decompose_essential(const double *E, double *R1, double *R2, double *t);
+int ora_recover_pose(const double *E, const float *p1, const float *p2, int n, double fx, double fy, double cx,
+                     double cy, double dist, int use_mask, uint8_t *mask, double *R, double *t);
 
 /* FeatureMatcher::match after kNN: ratio -> F-RANSAC mask -> 100 px motion
  * filter (reference src/feature_matcher.cpp:34-103).  Returns final count. */

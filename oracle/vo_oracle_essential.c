@@ -432,3 +432,181 @@ int ora_find_essential_ransac(const float *p1, const float *p2, int n, double fx
     free(q1); free(q2); free(err); free(cur);
     return max_good > 0;
 }
+
+/* ---- pose from an essential matrix ------------------------------------------ */
+
+/* Cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 4),
+ * row-major; on return A is diagonal and column j of V the eigenvector of
+ * A[j][j].  The GPU kernel performs the same operations in the same order. */
+static void jacobi_sym(double *A, double *V, int n)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                if (i != j) off += A[i * n + j] * A[i * n + j];
+                else diag += A[i * n + j] * A[i * n + j];
+            }
+        if (off <= 1e-30 * diag || off == 0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+static double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+/* [OCV-recall] cv::decomposeEssentialMat (five-point.cpp): E = U D Vt, U and
+ * Vt negated when their determinant is negative, W = [0 1 0; -1 0 0; 0 0 1],
+ * R1 = U W Vt, R2 = U W^T Vt, t = third column of U.  The SVD here comes from
+ * the Jacobi eigen-decomposition of E^T E (singular values descending, ties by
+ * index): u_i = E v_i / |E v_i| for the two leading pairs, u_2 = u_0 x u_1.
+ * A different SVD routine can exchange R1 and R2 or negate t; the set
+ * {R1, R2} x {t, -t} that ora_recover_pose chooses from is the same. */
+void ora_decompose_essential(const double *E, double *R1, double *R2, double *t)
+{
+    double A[9], V[9], U[9], Vt[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += E[k * 3 + i] * E[k * 3 + j];
+            A[i * 3 + j] = s;
+        }
+    jacobi_sym(A, V, 3);
+    int order[3] = {0, 1, 2};
+    for (int i = 0; i < 3; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (A[order[j] * 4] > A[order[i] * 4]) { const int o = order[i]; order[i] = order[j]; order[j] = o; }
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++) Vt[i * 3 + k] = V[k * 3 + order[i]];
+    for (int c = 0; c < 2; c++) {
+        double u[3], nrm = 0;
+        for (int i = 0; i < 3; i++) {
+            u[i] = E[i * 3 + 0] * Vt[c * 3 + 0] + E[i * 3 + 1] * Vt[c * 3 + 1] + E[i * 3 + 2] * Vt[c * 3 + 2];
+            nrm += u[i] * u[i];
+        }
+        nrm = sqrt(nrm);
+        for (int i = 0; i < 3; i++) U[i * 3 + c] = u[i] / nrm;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4]; /* u0 x u1: det(U) = +1 */
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    if (det3(Vt) < 0)
+        for (int i = 0; i < 9; i++) Vt[i] = -Vt[i];
+    /* U W = [-u1 u0 u2], U W^T = [u1 -u0 u2] (columns) */
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const double a = U[i * 3 + 1] * Vt[0 * 3 + j], b = U[i * 3 + 0] * Vt[1 * 3 + j], c = U[i * 3 + 2] * Vt[2 * 3 + j];
+            R1[i * 3 + j] = -a + b + c;
+            R2[i * 3 + j] = a - b + c;
+        }
+    for (int i = 0; i < 3; i++) t[i] = U[i * 3 + 2];
+}
+
+/* [OCV-recall] cv::triangulatePoints for one correspondence between
+ * P0 = [I | 0] and P = [R | t]: the right singular vector of the smallest
+ * singular value of the 4 x 4 system {x P[2] - P[0], y P[2] - P[1]} of both
+ * views, here the eigenvector of the smallest eigenvalue of A^T A (first
+ * minimum).  Its sign is arbitrary; the cheirality tests do not depend on it. */
+static void triangulate_one(const double *R, const double *t, double x1, double y1, double x2, double y2, double *Q)
+{
+    double A[4][4] = {{-1, 0, x1, 0}, {0, -1, y1, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int k = 0; k < 3; k++) {
+        A[2][k] = x2 * R[6 + k] - R[k];
+        A[3][k] = y2 * R[6 + k] - R[3 + k];
+    }
+    A[2][3] = x2 * t[2] - t[0];
+    A[3][3] = y2 * t[2] - t[1];
+    double M[16], V[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += A[k][i] * A[k][j];
+            M[i * 4 + j] = s;
+        }
+    jacobi_sym(M, V, 4);
+    int m = 0;
+    for (int i = 1; i < 4; i++)
+        if (M[i * 5] < M[m * 5]) m = i;
+    for (int k = 0; k < 4; k++) Q[k] = V[k * 4 + m];
+}
+
+/* cheirality test of cv::recoverPose for one triangulated point */
+static int cheirality_ok(const double *R, const double *t, const double *Q, double dist)
+{
+    int ok = Q[2] * Q[3] > 0;
+    const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+    ok &= Z < dist;
+    const double z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    ok &= z2 > 0;
+    ok &= z2 < dist;
+    return ok;
+}
+
+/* [OCV-recall] cv::recoverPose(E, p1, p2, K, R, t, mask) with
+ * distanceThresh = 50: the four (R, t) candidates of decomposeEssentialMat,
+ * each point triangulated under each, a candidate's votes = points in front of
+ * both cameras and nearer than the threshold (AND the incoming mask when
+ * use_mask), first candidate with the most votes wins in the order
+ * (R1,t) (R2,t) (R1,-t) (R2,-t).  p1/p2: n x 2 float32 pixels.  mask (n bytes)
+ * is read when use_mask and always written with the winner's 0/1 votes.
+ * Returns the number of votes. */
+int ora_recover_pose(const double *E, const float *p1, const float *p2, int n, double fx, double fy, double cx,
+                     double cy, double dist, int use_mask, uint8_t *mask, double *R, double *t)
+{
+    double R1[9], R2[9], tt[3], tn[3];
+    ora_decompose_essential(E, R1, R2, tt);
+    for (int i = 0; i < 3; i++) tn[i] = -tt[i];
+    const double *Rs[4] = {R1, R2, R1, R2};
+    const double *ts[4] = {tt, tt, tn, tn};
+    int good[4] = {0, 0, 0, 0};
+    uint8_t *votes = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        const double x1 = ((double)p1[2 * i] - cx) / fx, y1 = ((double)p1[2 * i + 1] - cy) / fy;
+        const double x2 = ((double)p2[2 * i] - cx) / fx, y2 = ((double)p2[2 * i + 1] - cy) / fy;
+        uint8_t v = 0;
+        for (int k = 0; k < 4; k++) {
+            double Q[4];
+            triangulate_one(Rs[k], ts[k], x1, y1, x2, y2, Q);
+            int ok = cheirality_ok(Rs[k], ts[k], Q, dist);
+            if (use_mask && !mask[i]) ok = 0;
+            v |= (uint8_t)(ok << k);
+            good[k] += ok;
+        }
+        votes[i] = v;
+    }
+    int best = 3;
+    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
+    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) best = 1;
+    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) best = 2;
+    memcpy(R, Rs[best], sizeof(double) * 9);
+    memcpy(t, ts[best], sizeof(double) * 3);
+    for (int i = 0; i < n; i++) mask[i] = (votes[i] >> best) & 1;
+    free(votes);
+    return good[best];
+}

@@ -486,3 +486,38 @@ def test_essential_ransac_labels_outliers(oracle):
     # exactly five points: the minimal solver once, every point an inlier of the accepted model
     ok5, E5, m5, it5 = oracle.find_essential_ransac(p1[n_out:n_out + 5], p2[n_out:n_out + 5], f, f, 640, 360)
     assert ok5 and m5.sum() == 5 and it5 == 1
+
+
+def test_recover_pose_known_motion(oracle):
+    """decomposeEssentialMat / recoverPose: proper rotations, the candidate set contains the truth, the cheirality
+    vote picks it for either sign and any scale of E, and distant points abstain."""
+    rng = np.random.default_rng(17)
+
+    def rot(a, b, c):
+        ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+        return (np.array([[cc, -sc, 0], [sc, cc, 0], [0, 0, 1]]) @ np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]]) @
+                np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]]))
+
+    for trial in range(6):
+        R = rot(*rng.uniform(-0.2, 0.2, 3))
+        t = rng.normal(size=3); t /= np.linalg.norm(t)
+        n = 120
+        X = np.c_[rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(4, 12, n)]
+        X[:20, 2] += 400  # far beyond 50 baselines
+        X2 = X @ R.T + t
+        p1 = 700 * X[:, :2] / X[:, 2:] + [640, 360]
+        p2 = 700 * X2[:, :2] / X2[:, 2:] + [640, 360]
+        E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+        R1, R2, tt = oracle.decompose_essential(E)
+        for Rc in (R1, R2):
+            assert np.abs(Rc @ Rc.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(Rc) - 1) < 1e-12
+        assert min(np.abs(R1 - R).max(), np.abs(R2 - R).max()) < 1e-9
+        assert min(np.abs(tt - t).max(), np.abs(tt + t).max()) < 1e-9
+        for Ein in (E, -2.0 * E):
+            good, Rr, tr, m = oracle.recover_pose(Ein, p1, p2, 700.0, 700.0, 640.0, 360.0)
+            assert np.abs(Rr - R).max() < 1e-5 and np.abs(tr - t).max() < 1e-5  # float32 pixels
+            assert m[20:].all() and good == m.sum() and m[:20].sum() <= 2
+        # the incoming mask is ANDed into the votes
+        keep = (np.arange(n) % 3 != 0).astype(np.uint8)
+        good, Rr, tr, m = oracle.recover_pose(E, p1, p2, 700.0, 700.0, 640.0, 360.0, mask=keep)
+        assert not (m & (1 - keep)).any() and good == m.sum()

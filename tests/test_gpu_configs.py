@@ -77,3 +77,42 @@ def test_kitti_eight_streams(ctx, oracle):
             _compare(ctx, res, s, ref)
             if nb:
                 assert ref["pnp_success"]
+
+
+def test_vga_pair_orb1000_match_essential_pose(ctx, oracle):
+    """The CPU-runnable configuration: one 640x480 gray pair, full detector with 1000 key points, brute-force
+    Hamming matching with the ratio test, findEssentialMat(RANSAC) and recoverPose; every stage against the
+    oracle and the pose against the rendered motion."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    seq = synth.make_sequence(cam, 4, seed=1001, channels=1, scene=synth.Scene(1001, relief=2.0))
+    g0, g1 = seq["frames"][0], seq["frames"][3]
+    feats = []
+    for g in (g0, g1):
+        k, d = ctx.detect_orb(g, 1000, 1.2, 8, 20)
+        k_r, d_r = oracle.orb_detect(g, 1000, 1.2, 8, 20)
+        assert np.array_equal(d, d_r) and np.array_equal(k.view(np.uint8), k_r.view(np.uint8))
+        feats.append((k, d))
+    (k0, d0), (k1, d1) = feats
+    m = ctx.match(k0, d0, k1, d1, 0.7)
+    m_r, _, _ = oracle.match_filter(oracle.knn2(d0, d1), len(k1), k0, k1, 0.7)
+    assert np.array_equal(m, m_r) and len(m) > 150
+    p0, p1 = np.c_[m["px"], m["py"]], np.c_[m["cx"], m["cy"]]
+    ok, E, mask, it = ctx.find_essential_ransac(p0, p1, *K)
+    ok_r, E_r, mask_r, it_r = oracle.find_essential_ransac(p0, p1, *K)
+    assert ok and ok_r and it == it_r and np.array_equal(mask, mask_r) and np.abs(E - E_r).max() < 1e-9
+    good, R, t, votes = ctx.recover_pose(E, p0, p1, *K, mask=mask)
+    good_r, R_r, t_r, votes_r = oracle.recover_pose(E, p0, p1, *K, mask=mask)
+    assert good == good_r and np.array_equal(votes, votes_r)
+    assert np.arccos(np.clip((np.trace(R @ R_r.T) - 1) / 2, -1, 1)) < 1e-6  # rad
+    assert np.abs(t - t_r).max() < 1e-6  # unit-norm translation
+    # rendered motion: X_curr = Rc Rp^T X_prev + Rc (cp - cc)
+    (Rp, cp), (Rc, cc) = seq["poses"][0], seq["poses"][3]
+    Rt, tt = Rc @ Rp.T, Rc @ (cp - cc)
+    tt = tt / np.linalg.norm(tt)
+    # a minimal-sample E (findEssentialMat does not refit on its inliers) of a 100 mm motion seen at 5 m:
+    # rotation and translation direction trade off against each other, so the bounds are loose
+    r_err = np.arccos(np.clip((np.trace(R @ Rt.T) - 1) / 2, -1, 1))
+    t_err = np.arccos(np.clip(t @ tt, -1, 1))
+    assert r_err < np.deg2rad(1.5) and t_err < np.deg2rad(45), (np.rad2deg(r_err), np.rad2deg(t_err))
+    assert good > 0.8 * mask.sum() > 80

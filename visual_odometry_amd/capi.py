@@ -78,6 +78,8 @@ EXPORTS = {
                                            C.c_double, C.c_double, C.c_int, _P, _P, _P, _P]),
     "vo_essential_hypotheses": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _P,
                                           C.c_int, C.c_double, _P, _P, _P]),
+    "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_double, C.c_int, _P, _P, _P, _P]),
     "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, _P, _P, _P, _P, C.c_int]),
     "vo_match_features_ex": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, _P, _P]),
@@ -215,6 +217,22 @@ class Context:
                                                        threshold, max_iters, _ptr(mask), _ptr(E),
                                                        C.addressof(found), C.addressof(iters)))
         return bool(found.value), E.reshape(3, 3), mask[:n].copy(), iters.value
+
+    def recover_pose(self, E, p1, p2, fx, fy, cx, cy, mask=None, distance_thresh=50.0):
+        """cv::recoverPose: (votes, R, t, mask of the winning candidate's votes)."""
+        E = np.ascontiguousarray(E, np.float64).reshape(9)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        m = np.zeros(max(n, 1), np.uint8)
+        if mask is not None:
+            m[:n] = np.asarray(mask, np.uint8).reshape(-1)[:n]
+        R, t = np.zeros(9, np.float64), np.zeros(3, np.float64)
+        good = C.c_int(0)
+        self._check(self._lib.vo_recover_pose(self._h, _ptr(E), _ptr(p1), _ptr(p2), n, fx, fy, cx, cy,
+                                              distance_thresh, int(mask is not None), _ptr(m), _ptr(R), _ptr(t),
+                                              C.addressof(good)))
+        return good.value, R.reshape(3, 3), t, m[:n].copy()
 
     def essential_hypotheses(self, p1, p2, fx, fy, cx, cy, samples, threshold=1.0):
         p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)

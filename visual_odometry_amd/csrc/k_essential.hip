@@ -495,6 +495,229 @@ __global__ __launch_bounds__(ER_THREADS) void k_e_ransac(const double *__restric
     }
 }
 
+// ---- pose from an essential matrix --------------------------------------------
+
+// cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (row-major):
+// A becomes diagonal, column j of V the eigenvector of A[j][j]
+template <int N>
+__device__ __forceinline__ void jacobi_sym(double (&A)[N * N], double (&V)[N * N])
+{
+#pragma unroll
+    for (int i = 0; i < N * N; i++) V[i] = (i % (N + 1) == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                if (i != j) off += A[i * N + j] * A[i * N + j];
+                else diag += A[i * N + j] * A[i * N + j];
+            }
+        if (off <= 1e-30 * diag || off == 0) break;
+#pragma unroll
+        for (int p = 0; p < N - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * N + q] - A[p * N + p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double akp = A[k * N + p], akq = A[k * N + q];
+                    A[k * N + p] = c * akp - sn * akq;
+                    A[k * N + q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double apk = A[p * N + k], aqk = A[q * N + k];
+                    A[p * N + k] = c * apk - sn * aqk;
+                    A[q * N + k] = sn * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double vkp = V[k * N + p], vkq = V[k * N + q];
+                    V[k * N + p] = c * vkp - sn * vkq;
+                    V[k * N + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// cv::decomposeEssentialMat: R1 = U W Vt, R2 = U W^T Vt, t = u2, with the SVD
+// taken from the eigen-decomposition of E^T E (u2 = u0 x u1, Vt negated when
+// its determinant is negative)
+__device__ void decompose_essential(const double *E, double *R1, double *R2, double *t)
+{
+    double A[9], V[9], U[9], Vt[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) s += E[k * 3 + i] * E[k * 3 + j];
+            A[i * 3 + j] = s;
+        }
+    jacobi_sym<3>(A, V);
+    double ev[3] = {A[0], A[4], A[8]};
+    double vc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) vc[i][k] = V[k * 3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i + 1; j < 3; j++)
+            if (ev[j] > ev[i]) {
+                const double x = ev[i]; ev[i] = ev[j]; ev[j] = x;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double u = vc[i][k]; vc[i][k] = vc[j][k]; vc[j][k] = u; }
+            }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) Vt[i * 3 + k] = vc[i][k];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        double u[3], nrm = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            u[i] = E[i * 3 + 0] * Vt[c * 3 + 0] + E[i * 3 + 1] * Vt[c * 3 + 1] + E[i * 3 + 2] * Vt[c * 3 + 2];
+            nrm += u[i] * u[i];
+        }
+        nrm = sqrt(nrm);
+#pragma unroll
+        for (int i = 0; i < 3; i++) U[i * 3 + c] = u[i] / nrm;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4];
+    U[5] = U[6] * U[1] - U[0] * U[7];
+    U[8] = U[0] * U[4] - U[3] * U[1];
+    const double det = Vt[0] * (Vt[4] * Vt[8] - Vt[5] * Vt[7]) - Vt[1] * (Vt[3] * Vt[8] - Vt[5] * Vt[6]) +
+                       Vt[2] * (Vt[3] * Vt[7] - Vt[4] * Vt[6]);
+    if (det < 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Vt[i] = -Vt[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double a = U[i * 3 + 1] * Vt[0 * 3 + j], b = U[i * 3 + 0] * Vt[1 * 3 + j],
+                         c = U[i * 3 + 2] * Vt[2 * 3 + j];
+            R1[i * 3 + j] = -a + b + c;
+            R2[i * 3 + j] = a - b + c;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] = U[i * 3 + 2];
+}
+
+// cv::triangulatePoints for one correspondence between [I | 0] and [R | t]
+// followed by the cheirality test of cv::recoverPose
+__device__ __forceinline__ bool triangulate_vote(const double *R, const double *t, double x1, double y1, double x2,
+                                                 double y2, double dist)
+{
+    double A[4][4] = {{-1, 0, x1, 0}, {0, -1, y1, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        A[2][k] = x2 * R[6 + k] - R[k];
+        A[3][k] = y2 * R[6 + k] - R[3 + k];
+    }
+    A[2][3] = x2 * t[2] - t[0];
+    A[3][3] = y2 * t[2] - t[1];
+    double M[16], V[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += A[k][i] * A[k][j];
+            M[i * 4 + j] = s;
+        }
+    jacobi_sym<4>(M, V);
+    double best = M[0];
+    double Q[4] = {V[0], V[4], V[8], V[12]};
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (M[i * 5] < best) {
+            best = M[i * 5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) Q[k] = V[k * 4 + i];
+        }
+    bool ok = Q[2] * Q[3] > 0;
+    const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+    ok = ok && Z < dist;
+    const double z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    ok = ok && z2 > 0 && z2 < dist;
+    return ok;
+}
+
+constexpr int RP_THREADS = 256;
+
+// cv::recoverPose for one problem: q = n x (x1, y1, x2, y2) normalised points,
+// mask is read when use_mask and rewritten with the winner's votes, votes is an
+// n-byte work array.  out = R (9, row-major) then t (3); info = {votes of the
+// winner, winner index in the order (R1,t) (R2,t) (R1,-t) (R2,-t)}.
+__global__ __launch_bounds__(RP_THREADS) void k_recover_pose(const double *__restrict__ E, const double *__restrict__ q,
+                                                            int n, double dist, int use_mask,
+                                                            uint8_t *__restrict__ mask, uint8_t *__restrict__ votes,
+                                                            double *__restrict__ out, int *__restrict__ info)
+{
+    __shared__ double s_R[2][9], s_t[2][3];
+    __shared__ int s_good[4], s_best;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double e[9], R1[9], R2[9], t[3];
+        for (int i = 0; i < 9; i++) e[i] = E[i];
+        decompose_essential(e, R1, R2, t);
+        for (int i = 0; i < 9; i++) { s_R[0][i] = R1[i]; s_R[1][i] = R2[i]; }
+        for (int i = 0; i < 3; i++) { s_t[0][i] = t[i]; s_t[1][i] = -t[i]; }
+    }
+    if (tid < 4) s_good[tid] = 0;
+    __syncthreads();
+    int cnt[4] = {0, 0, 0, 0};
+    const double4 *pts = reinterpret_cast<const double4 *>(q);
+    for (int i = tid; i < n; i += RP_THREADS) {
+        const double4 p = pts[i];
+        const bool live = !use_mask || mask[i] != 0;
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) {
+            double R[9], t[3];
+            for (int j = 0; j < 9; j++) R[j] = s_R[k & 1][j];
+            for (int j = 0; j < 3; j++) t[j] = s_t[k >> 1][j];
+            const bool ok = triangulate_vote(R, t, p.x, p.y, p.z, p.w, dist) && live;
+            v |= (uint32_t)ok << k;
+            cnt[k] += ok;
+        }
+        votes[i] = (uint8_t)v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int c = cnt[k];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if ((tid & 63) == 0) atomicAdd(&s_good[k], c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int g0 = s_good[0], g1 = s_good[1], g2 = s_good[2], g3 = s_good[3];
+        int best = 3;
+        if (g0 >= g1 && g0 >= g2 && g0 >= g3) best = 0;
+        else if (g1 >= g0 && g1 >= g2 && g1 >= g3) best = 1;
+        else if (g2 >= g0 && g2 >= g1 && g2 >= g3) best = 2;
+        s_best = best;
+        for (int i = 0; i < 9; i++) out[i] = s_R[best & 1][i];
+        for (int i = 0; i < 3; i++) out[9 + i] = s_t[best >> 1][i];
+        info[0] = s_good[best];
+        info[1] = best;
+    }
+    __syncthreads();
+    const int best = s_best;
+    for (int i = tid; i < n; i += RP_THREADS) mask[i] = (votes[i] >> best) & 1;
+}
+
 }  // namespace
 
 void launch_e_hypotheses(const double *q, int n, const int *idx, int H, double *E, int *n_models, float thr2,
@@ -512,6 +735,13 @@ void launch_e_ransac(const double *q, int n, const uint32_t *rng_raw, int rng_le
                               (int)sizeof(ErShared) + 64);
     hipLaunchKernelGGL(k_e_ransac, dim3(1), dim3(ER_THREADS), sizeof(ErShared) + 16, s, q, n, rng_raw, rng_len, prob,
                        thr2, max_iters, mask, E, info);
+}
+
+void launch_recover_pose(const double *E, const double *q, int n, double dist, int use_mask, uint8_t *mask,
+                         uint8_t *votes, double *out, int *info, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_recover_pose, dim3(1), dim3(RP_THREADS), 0, s, E, q, n, dist, use_mask, mask, votes, out,
+                       info);
 }
 
 }  // namespace vo

@@ -47,7 +47,7 @@ int vo_ctx::ensure_essential(int n_points, int n_hyp)
         if (d_emask) (void)hipFree(d_emask);
         d_eq = nullptr; d_emask = nullptr; e_pts_cap = 0;
         HIP_TRY(c, hipMalloc(&d_eq, sizeof(double) * 4 * (size_t)n_points));
-        HIP_TRY(c, hipMalloc(&d_emask, (size_t)n_points));
+        HIP_TRY(c, hipMalloc(&d_emask, 2 * (size_t)n_points));  // inlier mask, then per-candidate votes
         e_pts_cap = n_points;
     }
     if (!d_einfo) HIP_TRY(c, hipMalloc(&d_einfo, sizeof(int) * 4));
@@ -136,6 +136,35 @@ int vo_essential_hypotheses(vo_ctx *c, const float *p1, const float *p2, int n, 
     HIP_TRY(c, hipMemcpy(E, c->d_eE, sizeof(double) * 90 * (size_t)n_hyp, hipMemcpyDefault));
     HIP_TRY(c, hipMemcpy(n_models, c->d_enm, sizeof(int) * (size_t)n_hyp, hipMemcpyDefault));
     HIP_TRY(c, hipMemcpy(counts, c->d_ecnt, sizeof(int) * 10 * (size_t)n_hyp, hipMemcpyDefault));
+    return VO_OK;
+}
+
+int vo_recover_pose(vo_ctx *c, const double *E, const float *p1, const float *p2, int n, double fx, double fy,
+                    double cx, double cy, double distance_thresh, int use_mask, uint8_t *mask, double *R, double *t,
+                    int *n_good)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!E || !p1 || !p2 || !mask || !R || !t || n < 1 || !(fx > 0 && fy > 0) || !(distance_thresh > 0))
+        return bfail(c, VO_ERR_ARG, "vo_recover_pose: bad arguments (n %d)", n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = c->ensure_essential(n, 1);
+    if (rc) return rc;
+    if ((rc = upload_normalised(c, p1, p2, n, fx, fy, cx, cy))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_eE, E, sizeof(double) * 9, hipMemcpyDefault));
+    if (use_mask) HIP_TRY(c, hipMemcpy(c->d_emask, mask, (size_t)n, hipMemcpyDefault));
+    launch_recover_pose(c->d_eE, c->d_eq, n, distance_thresh, use_mask ? 1 : 0, c->d_emask, c->d_emask + c->e_pts_cap,
+                        c->d_eE + 16, c->d_einfo, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_recover_pose: %s", hipGetErrorString(e));
+    double out[12];
+    int info[2];
+    HIP_TRY(c, hipMemcpy(out, c->d_eE + 16, sizeof(out), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(info, c->d_einfo, sizeof(info), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(mask, c->d_emask, (size_t)n, hipMemcpyDefault));
+    memcpy(R, out, sizeof(double) * 9);
+    memcpy(t, out + 9, sizeof(double) * 3);
+    if (n_good) *n_good = info[0];
     return VO_OK;
 }
 

@@ -155,6 +155,8 @@ void launch_e_hypotheses(const double *q, int n, const int *idx, int H, double *
 // cv::findEssentialMat's RANSAC on one point set; info = {found, iters_run, n_inliers}
 void launch_e_ransac(const double *q, int n, const uint32_t *rng_raw, int rng_len, double prob, float thr2,
                      int max_iters, uint8_t *mask, double *E, int *info, hipStream_t s);
+void launch_recover_pose(const double *E, const double *q, int n, double dist, int use_mask, uint8_t *mask,
+                         uint8_t *votes, double *out, int *info, hipStream_t s);
 
 // ---- pose stage -------------------------------------------------------------
 
