@@ -5,6 +5,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "visual_odometry/vo_device.hpp"
 
@@ -56,13 +57,30 @@ public:
         return result;
     }
 
+    // Addition to the reference's interface: cv::undistort(gray, K, dist) for
+    // cameras that deliver raw frames (the reference's ZED frames arrive
+    // rectified, src/zed_interface.cpp:112).  dist = k1 k2 p1 p2 [k3 [k4 k5 k6]].
+    // The returned Mat shares this object's buffer.
+    cv::Mat undistort(const cv::Mat &gray, const CameraParams &cam, const std::vector<double> &dist)
+    {
+        if (gray.empty() || gray.channels() != 1)
+            throw std::runtime_error("ImageProcessor::undistort: 8-bit single-channel image expected");
+        const int w = gray.cols, h = gray.rows;
+        dev_.ensure(w, h, 16);
+        undistorted_buffer_.create(h, w, CV_8UC1);
+        dev_.check(vo_undistort(dev_.get(), gray.ptr<uint8_t>(0), w, h, (int)gray.step, cam.fx, cam.fy, cam.cx, cam.cy,
+                                dist.data(), (int)dist.size(), undistorted_buffer_.ptr<uint8_t>(0), w),
+                   "vo_undistort");
+        return undistorted_buffer_;
+    }
+
     void setGaussianBlurSize(int size) { gaussian_blur_size_ = size; }
     void setGaussianSigma(double sigma) { gaussian_sigma_ = sigma; }
     void setEnableHistogramEq(bool enable) { enable_histogram_eq_ = enable; }
 
 private:
     detail::DeviceContext dev_;
-    cv::Mat gray_buffer_, enhanced_buffer_, denoised_buffer_, masked_buffer_;
+    cv::Mat gray_buffer_, enhanced_buffer_, denoised_buffer_, masked_buffer_, undistorted_buffer_;
     int gaussian_blur_size_{3};
     double gaussian_sigma_{1.0};
     bool enable_histogram_eq_{false};

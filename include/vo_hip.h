@@ -218,6 +218,17 @@ int vo_image_process(vo_ctx *ctx, const uint8_t *src, int w, int h, int src_stri
                      double sigma, uint8_t *gray, uint8_t *enhanced,
                      uint8_t *denoised, uint8_t *masked, int out_stride);
 
+/* cv::undistort(gray, K, dist) of an 8-bit single-channel image: the inverse
+ * map of initUndistortRectifyMap (R = I, new camera matrix = K) quantised to
+ * 1/32 px, bilinear cv::remap with 15-bit fixed-point weights and a constant 0
+ * border.  dist = k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist 4, 5 or 8).  Not part of
+ * the reference's ImageProcessor (src/image_processor.cpp:6-79 has no
+ * undistortion; the ZED frames it receives are rectified,
+ * src/zed_interface.cpp:112): provided for cameras that deliver raw frames. */
+int vo_undistort(vo_ctx *ctx, const uint8_t *src, int w, int h, int src_stride,
+                 double fx, double fy, double cx, double cy, const double *dist, int n_dist,
+                 uint8_t *dst, int dst_stride);
+
 /* The same with an optional cross-check: a ratio-test survivor (i, j) is kept
  * only when i is also the nearest previous descriptor of j (mutual nearest
  * neighbours, ties to the lower index).  An extension: the reference creates

@@ -74,6 +74,8 @@ def lib():
         _lib.ora_recover_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]
+        _lib.ora_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -145,6 +147,17 @@ def roi_mask(g: np.ndarray) -> np.ndarray:
     h, w = g.shape
     out = np.empty((h, w), np.uint8)
     lib().ora_roi_mask(_p(g), w, h, w, _p(out), w)
+    return out
+
+
+def undistort(g, fx, fy, cx, cy, dist):
+    """cv::undistort(gray, K, dist) with dist = k1 k2 p1 p2 [k3 [k4 k5 k6]]."""
+    g = np.ascontiguousarray(g, np.uint8)
+    h, w = g.shape
+    d = np.ascontiguousarray(dist, np.float64).reshape(-1)
+    out = np.zeros_like(g)
+    if not lib().ora_undistort(_p(g), w, h, w, fx, fy, cx, cy, _p(d), len(d), _p(out), w):
+        raise ValueError("4, 5 or 8 distortion coefficients expected")
     return out
 
 

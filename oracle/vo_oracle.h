@@ -115,6 +115,9 @@ int ora_gaussian_blur(const uint8_t *src, int w, int h, int stride, int n, doubl
                       int dstride);
 /* zero outside rows [h/4, 3h/4] */
 void ora_roi_mask(const uint8_t *src, int w, int h, int stride, uint8_t *dst, int dstride);
+/* cv::undistort of an 8-bit gray image; dist = k1 k2 p1 p2 [k3 [k4 k5 k6]] */
+int ora_undistort(const uint8_t *src, int w, int h, int stride, double fx, double fy, double cx, double cy,
+                  const double *dist, int n_dist, uint8_t *dst, int dstride);
 
 /* ---- matching ------------------------------------------------------- */
 

@@ -501,3 +501,57 @@ void ora_roi_mask(const uint8_t *src, int w, int h, int stride, uint8_t *dst, in
         for (int x = 0; x < w; x++)
             dst[(size_t)y * dstride + x] = (y >= y0 && y <= y1) ? src[(size_t)y * stride + x] : 0;
 }
+
+/* ---- undistort -------------------------------------------------------------- */
+
+/* [OCV-recall] cv::undistort(src, dst, K, D) on an 8-bit single-channel image:
+ * initUndistortRectifyMap(K, D, I, K, CV_16SC2) followed by
+ * remap(INTER_LINEAR, BORDER_CONSTANT, 0).
+ *   map: for destination pixel (j, i): x = (j - cx)/fx, y = (i - cy)/fy,
+ *        r2 = x^2 + y^2, kr = (1 + ((k3 r2 + k2) r2 + k1) r2) / (1 + ((k6 r2 + k5) r2 + k4) r2),
+ *        xd = x kr + p1 2xy + p2 (r2 + 2x^2), yd = y kr + p1 (r2 + 2y^2) + p2 2xy,
+ *        u = fx xd + cx, v = fy yd + cy, all in double;
+ *        iu = cvRound(u * 32), iv = cvRound(v * 32): integer parts (>> 5, kept
+ *        as int16) and 5-bit fractions.
+ *   remap: weights (32-a)(32-b), a(32-b), (32-a)b, ab times 32 (sum 2^15; the
+ *        int16 table clamps the a = b = 0 weight to 32767, which changes no
+ *        8-bit result), taps outside the image read 0,
+ *        result (sum + 2^14) >> 15.
+ * dist holds k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist = 4, 5 or 8).
+ * OpenCV evaluates x by repeated addition of 1/fx along a row, processes the
+ * image in stripes with a shifted principal point and inverts K numerically;
+ * those differ from the closed forms used here by rounding only, which moves a
+ * result only where u * 32 or v * 32 falls on a rounding boundary. */
+int ora_undistort(const uint8_t *src, int w, int h, int stride, double fx, double fy, double cx, double cy,
+                  const double *dist, int n_dist, uint8_t *dst, int dstride)
+{
+    if (n_dist != 4 && n_dist != 5 && n_dist != 8) return 0;
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+    const double k3 = n_dist >= 5 ? dist[4] : 0.0;
+    const double k4 = n_dist >= 8 ? dist[5] : 0.0, k5 = n_dist >= 8 ? dist[6] : 0.0, k6 = n_dist >= 8 ? dist[7] : 0.0;
+    const double ifx = 1.0 / fx, ify = 1.0 / fy;
+    for (int i = 0; i < h; i++) {
+        const double y = (i - cy) * ify;
+        for (int j = 0; j < w; j++) {
+            const double x = (j - cx) * ifx;
+            const double x2 = x * x, y2 = y * y, r2 = x2 + y2, xy2 = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            const double xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2);
+            const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2;
+            double u = (fx * xd + cx) * 32, v = (fy * yd + cy) * 32;
+            /* saturate_cast<int>, then the int16 store of the integer part */
+            u = u < -2147483648.0 ? -2147483648.0 : (u > 2147483647.0 ? 2147483647.0 : u);
+            v = v < -2147483648.0 ? -2147483648.0 : (v > 2147483647.0 ? 2147483647.0 : v);
+            const int iu = isnan(u) ? 0 : (int)lrint(u), iv = isnan(v) ? 0 : (int)lrint(v);
+            const int sx = (int16_t)(iu >> 5), sy = (int16_t)(iv >> 5), a = iu & 31, b = iv & 31;
+            int acc = 0;
+            for (int t = 0; t < 4; t++) {
+                const int xx = sx + (t & 1), yy = sy + (t >> 1);
+                const int wt = ((t & 1) ? a : 32 - a) * ((t >> 1) ? b : 32 - b) * 32;
+                if (xx >= 0 && xx < w && yy >= 0 && yy < h) acc += src[(size_t)yy * stride + xx] * wt;
+            }
+            dst[(size_t)i * dstride + j] = (uint8_t)((acc + (1 << 14)) >> 15);
+        }
+    }
+    return 1;
+}

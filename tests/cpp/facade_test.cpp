@@ -100,6 +100,8 @@ int main(int argc, char **argv)
             vo::ProcessedImages p2 = ip.processImage(bgr, true);
             std::printf("improc histeq5 %llx %llx %llx %llx\n", fnv1a(p2.gray), fnv1a(p2.enhanced), fnv1a(p2.denoised),
                         fnv1a(p2.masked));
+            cv::Mat und = ip.undistort(p0.gray, cam, {-0.28, 0.09, 0.0012, -0.0007, -0.015});
+            std::printf("improc undistort %llx\n", fnv1a(und));
             ip.setGaussianBlurSize(4);
             try {
                 ip.processImage(bgr, true);

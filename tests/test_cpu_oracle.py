@@ -521,3 +521,33 @@ def test_recover_pose_known_motion(oracle):
         keep = (np.arange(n) % 3 != 0).astype(np.uint8)
         good, Rr, tr, m = oracle.recover_pose(E, p1, p2, 700.0, 700.0, 640.0, 360.0, mask=keep)
         assert not (m & (1 - keep)).any() and good == m.sum()
+
+
+def test_undistort_semantics(oracle):
+    """Zero distortion is the identity; otherwise the result is the bilinear sample of the source at the forward
+    distortion model's position, to within rounding of a float64 evaluation (1/32 px map quantisation)."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    g = synth.make_sequence(cam, 1, seed=9, channels=1)["frames"][0]
+    # smooth the test image so that the 1/32 px quantisation of the map stays below a grey level
+    gs = oracle.gaussian_blur(g, 9, 2.5)
+    assert np.array_equal(oracle.undistort(gs, cam.fx, cam.fy, cam.cx, cam.cy, [0, 0, 0, 0]), gs)
+    k1, k2, p1, p2, k3 = dist = [-0.25, 0.07, 0.001, -0.0015, 0.01]
+    out = oracle.undistort(gs, cam.fx, cam.fy, cam.cx, cam.cy, dist)
+    jj, ii = np.meshgrid(np.arange(cam.width), np.arange(cam.height))
+    x, y = (jj - cam.cx) / cam.fx, (ii - cam.cy) / cam.fy
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    u = cam.fx * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + cam.cx
+    v = cam.fy * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + cam.cy
+    inside = (u >= 0) & (u < cam.width - 1) & (v >= 0) & (v < cam.height - 1)
+    u0, v0 = np.floor(u).astype(int).clip(0, cam.width - 2), np.floor(v).astype(int).clip(0, cam.height - 2)
+    a, b = u - u0, v - v0
+    f = gs.astype(np.float64)
+    ref = (f[v0, u0] * (1 - a) * (1 - b) + f[v0, u0 + 1] * a * (1 - b) + f[v0 + 1, u0] * (1 - a) * b +
+           f[v0 + 1, u0 + 1] * a * b)
+    assert inside.mean() > 0.95
+    err = np.abs(out.astype(np.float64) - ref)[inside]
+    assert err.max() <= 1.5 and err.mean() < 0.3  # rounding to u8 (0.5) + map quantisation (1/64 px x gradient)
+    # a source position outside the image reads the constant border 0
+    far = oracle.undistort(gs, cam.fx, cam.fy, cam.cx, cam.cy, [2.0, 1.0, 0, 0])
+    assert far[0, 0] == 0 and far[-1, -1] == 0 and far[cam.height // 2, cam.width // 2] == gs[cam.height // 2, cam.width // 2]

@@ -97,6 +97,8 @@ def test_frame_processor_facade_matches_oracle(oracle, imu_tx):
     for key, kw in (("default", {}), ("histeq5", dict(hist_eq=True, blur_size=5, sigma=1.4))):
         r = oracle.process_image(bgr0, enhance=True, **kw)
         assert ip[key] == [fnv(r[k]) for k in ("gray", "enhanced", "denoised", "masked")]
+    assert ip["undistort"] == [fnv(oracle.undistort(g0, cam.fx, cam.fy, cam.cx, cam.cy,
+                                                    [-0.28, 0.09, 0.0012, -0.0007, -0.015]))]
     assert "improc_even threw" in lines
 
     # error conventions: detectFeatures swallows and returns empty, processFrame throws

@@ -256,3 +256,21 @@ def test_match_features_with_few_survivors(ctx, oracle, vga_seq):
     assert 8 <= n_ratio <= 14 and len(m_ref) >= 7
     m = ctx.match(ks, ds, k1, d1, 0.7)
     assert np.array_equal(m, m_ref)
+
+
+@pytest.mark.parametrize("cam_name,dist", [
+    ("vga", [0.0, 0.0, 0.0, 0.0]),
+    ("vga", [-0.28, 0.09, 0.0012, -0.0007, -0.015]),
+    ("hd720", [0.12, -0.05, -0.002, 0.003, 0.01, 0.02, -0.01, 0.004]),
+    ("kitti", [0.9, 0.4, 0.01, 0.01, 0.2]),  # strong pincushion: taps leave the image
+])
+def test_undistort_bit_exact(ctx, oracle, cam_name, dist):
+    cam = synth.CONFIG_CAMERAS[cam_name]
+    g = synth.make_sequence(cam, 1, seed=77, channels=1)["frames"][0]
+    ref = oracle.undistort(g, cam.fx, cam.fy, cam.cx, cam.cy, dist)
+    out = ctx.undistort(g, cam.fx, cam.fy, cam.cx, cam.cy, dist)
+    assert np.array_equal(out, ref)
+    if not any(dist):
+        assert np.array_equal(out, g)
+    with pytest.raises(Exception):
+        ctx.undistort(g, cam.fx, cam.fy, cam.cx, cam.cy, [0.1, 0.2, 0.3])

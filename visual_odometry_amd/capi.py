@@ -78,6 +78,8 @@ EXPORTS = {
                                            C.c_double, C.c_double, C.c_int, _P, _P, _P, _P]),
     "vo_essential_hypotheses": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _P,
                                           C.c_int, C.c_double, _P, _P, _P]),
+    "vo_undistort": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _P,
+                               C.c_int, _P, C.c_int]),
     "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_int, _P, _P, _P, _P]),
     "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -217,6 +219,15 @@ class Context:
                                                        threshold, max_iters, _ptr(mask), _ptr(E),
                                                        C.addressof(found), C.addressof(iters)))
         return bool(found.value), E.reshape(3, 3), mask[:n].copy(), iters.value
+
+    def undistort(self, gray, fx, fy, cx, cy, dist):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        d = np.ascontiguousarray(dist, np.float64).reshape(-1)
+        out = np.zeros_like(gray)
+        self._check(self._lib.vo_undistort(self._h, _ptr(gray), w, h, w, fx, fy, cx, cy, _ptr(d), len(d), _ptr(out),
+                                           w))
+        return out
 
     def recover_pose(self, E, p1, p2, fx, fy, cx, cy, mask=None, distance_thresh=50.0):
         """cv::recoverPose: (votes, R, t, mask of the winning candidate's votes)."""

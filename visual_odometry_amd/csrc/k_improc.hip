@@ -155,6 +155,51 @@ __global__ __launch_bounds__(IP_THREADS) void k_enhance_blur_mask(const uint8_t 
     }
 }
 
+// cv::undistort of a gray plane: the inverse map of initUndistortRectifyMap
+// (K, D, R = I, P = K) evaluated per destination pixel in double, quantised to
+// 1/32 px like the CV_16SC2 + CV_16UC1 maps, then cv::remap(INTER_LINEAR,
+// BORDER_CONSTANT 0) with the 15-bit fixed-point bilinear weights.  A thread
+// produces four neighbouring pixels of a row (one dword store); the taps are
+// gathers through L1/L2 -- neighbouring threads read neighbouring source bytes.
+struct UndistortParams {
+    double fx, fy, cx, cy, ifx, ify;
+    double k1, k2, p1, p2, k3, k4, k5, k6;
+};
+
+__global__ __launch_bounds__(IP_THREADS) void k_undistort(const uint8_t *__restrict__ src, int w, int h, int spitch,
+                                                         UndistortParams P, uint8_t *__restrict__ dst, int dpitch)
+{
+    const int j0 = (blockIdx.x * 32 + (threadIdx.x & 31)) * 4;
+    const int i = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (i >= h || j0 >= w) return;
+    const double y = (i - P.cy) * P.ify;
+    const double y2 = y * y;
+    uint32_t out = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = j0 + q;
+        const double x = (j - P.cx) * P.ifx;
+        const double x2 = x * x, r2 = x2 + y2, xy2 = 2 * x * y;
+        const double kr = (1 + ((P.k3 * r2 + P.k2) * r2 + P.k1) * r2) / (1 + ((P.k6 * r2 + P.k5) * r2 + P.k4) * r2);
+        const double xd = x * kr + P.p1 * xy2 + P.p2 * (r2 + 2 * x2);
+        const double yd = y * kr + P.p1 * (r2 + 2 * y2) + P.p2 * xy2;
+        double u = (P.fx * xd + P.cx) * 32, v = (P.fy * yd + P.cy) * 32;
+        u = u < -2147483648.0 ? -2147483648.0 : (u > 2147483647.0 ? 2147483647.0 : u);
+        v = v < -2147483648.0 ? -2147483648.0 : (v > 2147483647.0 ? 2147483647.0 : v);
+        const int iu = (u != u) ? 0 : (int)rint(u), iv = (v != v) ? 0 : (int)rint(v);
+        const int sx = (int)(int16_t)(iu >> 5), sy = (int)(int16_t)(iv >> 5), a = iu & 31, b = iv & 31;
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int xx = sx + (t & 1), yy = sy + (t >> 1);
+            const int wt = ((t & 1) ? a : 32 - a) * ((t >> 1) ? b : 32 - b) * 32;
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h) acc += (int)src[(size_t)yy * spitch + xx] * wt;
+        }
+        out |= (uint32_t)((acc + (1 << 14)) >> 15) << (8 * q);
+    }
+    *reinterpret_cast<uint32_t *>(dst + (size_t)i * dpitch + j0) = out;  // the pitch is padded to 128
+}
+
 }  // namespace
 
 void launch_hist256(const uint8_t *img, int w, int h, int pitch, uint32_t *hist, hipStream_t s)
@@ -177,6 +222,14 @@ void launch_enhance_blur_mask(const uint8_t *src, int w, int h, int pitch, const
     for (int i = 0; i < n_taps; i++) t.w[i] = taps[i];
     hipLaunchKernelGGL(k_enhance_blur_mask, dim3((w + IP_TW - 1) / IP_TW, (h + IP_TH - 1) / IP_TH),
                        dim3(IP_THREADS), 0, s, src, w, h, pitch, lut, t, enh, den, msk);
+}
+
+void launch_undistort(const uint8_t *src, int w, int h, int spitch, double fx, double fy, double cx, double cy,
+                      const double *k, uint8_t *dst, int dpitch, hipStream_t s)
+{
+    UndistortParams P{fx, fy, cx, cy, 1.0 / fx, 1.0 / fy, k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]};
+    hipLaunchKernelGGL(k_undistort, dim3((w + 127) / 128, (h + 7) / 8), dim3(IP_THREADS), 0, s, src, w, h, spitch, P,
+                       dst, dpitch);
 }
 
 }  // namespace vo

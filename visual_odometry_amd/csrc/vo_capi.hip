@@ -348,6 +348,24 @@ int vo_image_process(vo_ctx *c, const uint8_t *src, int w, int h, int src_stride
     return finish(c, "vo_image_process");
 }
 
+int vo_undistort(vo_ctx *c, const uint8_t *src, int w, int h, int src_stride, double fx, double fy, double cx,
+                 double cy, const double *dist, int n_dist, uint8_t *dst, int dst_stride)
+{
+    int rc = check_frame(c, w, h, "vo_undistort");
+    if (rc) return rc;
+    if (!src || !dst || !dist || src_stride < w || dst_stride < w || !(fx > 0 && fy > 0))
+        return fail(c, VO_ERR_ARG, "vo_undistort: bad arguments");
+    if (n_dist != 4 && n_dist != 5 && n_dist != 8)
+        return fail(c, VO_ERR_UNSUPPORTED, "vo_undistort: %d distortion coefficients (4, 5 or 8 expected)", n_dist);
+    double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist; i++) k[i] = dist[i];
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_gray, c->pitch, src, src_stride, w, h, hipMemcpyDefault, c->stream));
+    launch_undistort(c->d_gray, w, h, (int)c->pitch, fx, fy, cx, cy, k, c->d_aux, (int)c->pitch, c->stream);
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->d_aux, c->pitch, w, h, hipMemcpyDefault, c->stream));
+    return finish(c, "vo_undistort");
+}
+
 int vo_detect(vo_ctx *c, const uint8_t *gray, int w, int h, int stride, int max_features, int fast_threshold,
               vo_kp *kps, uint8_t *desc, int *n_out)
 {

@@ -125,6 +125,11 @@ void launch_equalize_lut(const uint32_t *hist, int total, uint8_t *lut, hipStrea
 void launch_enhance_blur_mask(const uint8_t *src, int w, int h, int pitch, const uint8_t *lut, int n_taps,
                               const uint16_t *taps, uint8_t *enh, uint8_t *den, uint8_t *msk, hipStream_t s);
 
+// cv::undistort of a gray plane (k = k1 k2 p1 p2 k3 k4 k5 k6); dst rows must be
+// padded to a multiple of 128 bytes
+void launch_undistort(const uint8_t *src, int w, int h, int spitch, double fx, double fy, double cx, double cy,
+                      const double *k, uint8_t *dst, int dpitch, hipStream_t s);
+
 // Merge the split partials into vo_knn2 records, apply the ratio test (and,
 // when partial_rev holds the kNN of the swapped pair, the mutual-nearest
 // cross-check) and write the surviving matches in query order.
