@@ -229,6 +229,28 @@ int vo_undistort(vo_ctx *ctx, const uint8_t *src, int w, int h, int src_stride,
                  double fx, double fy, double cx, double cy, const double *dist, int n_dist,
                  uint8_t *dst, int dst_stride);
 
+/* Stereo front end: depth for the key points of the left image of a rectified
+ * rig.  Not part of the reference, whose depth plane comes from the ZED SDK
+ * (src/zed_interface.cpp:84-85); it produces the depth that
+ * FrameProcessor::backprojectAndFilter samples at the rounded key point
+ * (src/frame_processor.cpp:230-308), for cameras without such an SDK.
+ * Candidates of left key point i are the right key points j with
+ * |yL - yR| <= band and min_disp <= xL - xR <= max_disp; the best is the
+ * smallest Hamming-256 distance (ties: lowest j), it must pass
+ * d0 < ratio * d1 against the second candidate when there is one, and i must
+ * be the best left candidate of j under the same rule (cross-check).
+ * Per left key point: right_idx (-1 if unmatched), disparity = xL - xR (-1),
+ * depth = fx * baseline / disparity in the unit of baseline (NaN).  plane, if
+ * not null, is a dense w x h float32 image (host or device memory, row stride
+ * w): NaN except at (round(xL), round(yL)) of the matched key points, where it
+ * holds the depth (the nearest one when several share a pixel); it can be
+ * handed to vo_batch_submit as the depth of that frame. */
+int vo_stereo_depth(vo_ctx *ctx, const vo_kp *left_kps, const uint8_t *left_desc, int n_left,
+                    const vo_kp *right_kps, const uint8_t *right_desc, int n_right, double fx,
+                    double baseline, float band, float min_disp, float max_disp, float ratio,
+                    int32_t *right_idx, float *disparity, float *depth, float *plane, int w, int h,
+                    int *n_matched);
+
 /* The same with an optional cross-check: a ratio-test survivor (i, j) is kept
  * only when i is also the nearest previous descriptor of j (mutual nearest
  * neighbours, ties to the lower index).  An extension: the reference creates

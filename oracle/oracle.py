@@ -76,6 +76,12 @@ def lib():
                                           C.c_void_p]
         _lib.ora_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                        C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        _lib.ora_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.c_double, C.c_double, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        _lib.ora_stereo_depth_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_int]
+        _lib.ora_stereo_depth_plane.restype = None
         _lib.ora_ratio_test.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     return _lib
@@ -368,6 +374,25 @@ def recover_pose(E, p1, p2, fx, fy, cx, cy, mask=None, distance_thresh=50.0):
     good = lib().ora_recover_pose(_p(E), _p(p1), _p(p2), n, fx, fy, cx, cy, distance_thresh,
                                   int(mask is not None), _p(m), _p(R), _p(t))
     return good, R.reshape(3, 3), t, m[:n].copy()
+
+
+def stereo_match(lk, ld, rk, rd, fx, baseline, band=2.0, min_disp=1.0, max_disp=256.0, ratio=0.8, size=None):
+    """Band-limited left/right matching with cross-check: (right_idx, disparity, depth[, depth plane])."""
+    lk, rk = np.ascontiguousarray(lk, KP_DTYPE), np.ascontiguousarray(rk, KP_DTYPE)
+    ld, rd = np.ascontiguousarray(ld, np.uint8), np.ascontiguousarray(rd, np.uint8)
+    nl = len(lk)
+    ridx = np.zeros(max(nl, 1), np.int32)
+    disp = np.zeros(max(nl, 1), np.float32)
+    depth = np.zeros(max(nl, 1), np.float32)
+    lib().ora_stereo_match(_p(lk), _p(ld), nl, _p(rk), _p(rd), len(rk), band, min_disp, max_disp, ratio, fx, baseline,
+                           _p(ridx), _p(disp), _p(depth))
+    out = (ridx[:nl].copy(), disp[:nl].copy(), depth[:nl].copy())
+    if size is None:
+        return out
+    w, h = size
+    plane = np.zeros((h, w), np.float32)
+    lib().ora_stereo_depth_plane(_p(lk), _p(depth), nl, w, h, _p(plane), w)
+    return out + (plane,)
 
 
 def match_filter(knn, nt, qk, tk, ratio=0.7, knn_rev=None):

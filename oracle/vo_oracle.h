@@ -174,6 +174,14 @@ void ora_decompose_essential(const double *E, double *R1, double *R2, double *t)
 int ora_recover_pose(const double *E, const float *p1, const float *p2, int n, double fx, double fy, double cx,
                      double cy, double dist, int use_mask, uint8_t *mask, double *R, double *t);
 
+/* stereo front end (no counterpart in the reference, whose depth comes from
+ * the ZED SDK): band-limited left/right matching with cross-check,
+ * disparity -> depth, sparse depth plane */
+int ora_stereo_match(const ora_kp *lk, const uint8_t *ld, int nl, const ora_kp *rk, const uint8_t *rd, int nr,
+                     float band, float min_disp, float max_disp, float ratio, double fx, double baseline,
+                     int32_t *right_idx, float *disparity, float *depth);
+void ora_stereo_depth_plane(const ora_kp *lk, const float *depth, int nl, int w, int h, float *plane, int stride);
+
 /* FeatureMatcher::match after kNN: ratio -> F-RANSAC mask -> 100 px motion
  * filter (reference src/feature_matcher.cpp:34-103).  Returns final count. */
 int ora_match_filter(const ora_knn2 *knn, int nq, int nt, const ora_kp *qk,

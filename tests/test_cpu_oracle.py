@@ -551,3 +551,46 @@ def test_undistort_semantics(oracle):
     # a source position outside the image reads the constant border 0
     far = oracle.undistort(gs, cam.fx, cam.fy, cam.cx, cam.cy, [2.0, 1.0, 0, 0])
     assert far[0, 0] == 0 and far[-1, -1] == 0 and far[cam.height // 2, cam.width // 2] == gs[cam.height // 2, cam.width // 2]
+
+
+def test_stereo_match_semantics(oracle):
+    """Band-limited matching with cross-check against a numpy brute force on random descriptors, and the depth of a
+    synthetic rig against the rendered depth."""
+    rng = np.random.default_rng(12)
+    nl, nr = 300, 280
+    from oracle.oracle import KP_DTYPE
+    lk, rk = np.zeros(nl, KP_DTYPE), np.zeros(nr, KP_DTYPE)
+    lk["x"], lk["y"] = rng.integers(40, 600, nl), rng.integers(0, 40, nl)
+    rk["x"], rk["y"] = rng.integers(0, 600, nr), rng.integers(0, 40, nr)
+    ld = rng.integers(0, 256, (nl, 32), dtype=np.uint8)
+    rd = rng.integers(0, 256, (nr, 32), dtype=np.uint8)
+    rd[:120] = ld[:120] ^ (rng.random((120, 32)) < 0.02).astype(np.uint8)  # near-copies: true partners
+    rk["y"][:120] = lk["y"][:120] + rng.integers(-1, 2, 120)
+    rk["x"][:120] = lk["x"][:120] - rng.integers(2, 40, 120)
+    band, dmin, dmax, ratio = 2.0, 1.0, 64.0, 0.8
+    ridx, disp, depth = oracle.stereo_match(lk, ld, rk, rd, 700.0, 120.0, band, dmin, dmax, ratio)
+    D = np.unpackbits(ld[:, None, :] ^ rd[None, :, :], axis=2).sum(2).astype(np.int64)
+    dx = lk["x"][:, None] - rk["x"][None, :]
+    ok = (np.abs(lk["y"][:, None] - rk["y"][None, :]) <= band) & (dx >= dmin) & (dx <= dmax)
+    Dm = np.where(ok, D, 1 << 20)
+    exp = np.full(nl, -1)
+    for i in range(nl):
+        order = np.lexsort((np.arange(nr), Dm[i]))
+        j = order[0]
+        if Dm[i, j] >= 1 << 20:
+            continue
+        if Dm[i, order[1]] < 1 << 20 and not np.float32(Dm[i, j]) < np.float32(ratio) * np.float32(Dm[i, order[1]]):
+            continue
+        col = Dm[:, j]
+        if np.lexsort((np.arange(nl), col))[0] == i:
+            exp[i] = j
+    assert np.array_equal(ridx, exp) and (exp[:120] == np.arange(120)).mean() > 0.9
+    m = ridx >= 0
+    assert np.array_equal(disp[m], (lk["x"][m] - rk["x"][ridx[m]]).astype(np.float32))
+    assert np.allclose(depth[m], 700.0 * 120.0 / disp[m], rtol=1e-6) and np.isnan(depth[~m]).all()
+    # the plane keeps the nearest depth of a pixel
+    lk2 = lk.copy(); lk2["x"][:2], lk2["y"][:2] = 100, 20
+    plane = np.zeros((40, 640), np.float32)
+    dep = np.full(nl, np.nan, np.float32); dep[0], dep[1] = 900.0, 700.0
+    oracle.lib().ora_stereo_depth_plane(lk2.ctypes.data, dep.ctypes.data, nl, 640, 40, plane.ctypes.data, 640)
+    assert plane[20, 100] == 700.0 and np.isnan(plane).sum() == plane.size - 1

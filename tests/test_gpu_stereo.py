@@ -1,0 +1,101 @@
+"""Stereo front end: band-limited left/right matching with cross-check, disparity -> depth and the sparse depth
+plane, against the oracle; then the pipeline's pose from stereo depth alone against the rendered motion."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BASELINE_MM = 120.0
+
+
+def _nan_equal(a, b):
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+def _detect_pair(ctx, oracle, cam, seed, n_kp, f=0):
+    left, right = synth.make_stereo_sequence(cam, f + 1, seed=seed, channels=4, baseline_mm=BASELINE_MM)
+    out = []
+    for s in (left, right):
+        g = oracle.gray(s["frames"][f])
+        out.append(ctx.detect_orb(g, n_kp, 1.2, 8, 20))
+    return left, right, out[0], out[1]
+
+
+@pytest.mark.parametrize("cam_name,n_kp,band,ratio", [("hd720", 2000, 2.0, 0.8), ("hd1080", 4000, 1.0, 0.7),
+                                                      ("kitti", 1500, 3.0, 1.0)])
+def test_stereo_depth_matches_oracle(ctx, oracle, cam_name, n_kp, band, ratio):
+    cam = synth.CONFIG_CAMERAS[cam_name]
+    left, right, (kl, dl), (kr, dr) = _detect_pair(ctx, oracle, cam, 3100 + n_kp, n_kp)
+    size = (cam.width, cam.height)
+    ref = oracle.stereo_match(kl, dl, kr, dr, cam.fx, BASELINE_MM, band, 1.0, 256.0, ratio, size=size)
+    got = ctx.stereo_depth(kl, dl, kr, dr, cam.fx, BASELINE_MM, band, 1.0, 256.0, ratio, size=size)
+    assert np.array_equal(got[0], ref[0])          # right index per left key point
+    assert np.array_equal(got[1], ref[1])          # disparity (float32, exact)
+    assert _nan_equal(got[2], ref[2])              # depth (float32, exact)
+    assert _nan_equal(got[3], ref[3])              # sparse depth plane
+    m = got[0] >= 0
+    assert m.sum() > 0.4 * len(kl)
+    # one-to-one, inside the band, positive disparity
+    assert len(np.unique(got[0][m])) == m.sum()
+    assert np.abs(kl["y"][m] - kr["y"][got[0][m]]).max() <= band and got[1][m].min() >= 1.0
+    # against the rendered depth: disparity is quantised to the key points' pixel grid
+    true = left["depth"][0][np.rint(kl["y"][m]).astype(int), np.rint(kl["x"][m]).astype(int)]
+    rel = np.abs(got[2][m] - true) / true
+    assert np.median(rel) < 0.04 and (rel > 0.25).mean() < 0.02
+
+
+def test_stereo_depth_edge_cases(ctx, oracle):
+    cam = synth.CONFIG_CAMERAS["vga"]
+    left, right, (kl, dl), (kr, dr) = _detect_pair(ctx, oracle, cam, 77, 500)
+    # no right key points: nothing matches, the plane is all NaN
+    ridx, disp, depth, plane = ctx.stereo_depth(kl, dl, kr[:0], dr[:0], cam.fx, BASELINE_MM, size=(cam.width, cam.height))
+    assert (ridx == -1).all() and (disp == -1).all() and np.isnan(depth).all() and np.isnan(plane).all()
+    # no left key points
+    ridx, disp, depth = ctx.stereo_depth(kl[:0], dl[:0], kr, dr, cam.fx, BASELINE_MM)
+    assert len(ridx) == 0
+    # a disparity window that excludes everything
+    ridx, _, _ = ctx.stereo_depth(kl, dl, kr, dr, cam.fx, BASELINE_MM, min_disp=500.0, max_disp=600.0)
+    assert (ridx == -1).all()
+    # swapping the images leaves no positive disparities
+    ref = oracle.stereo_match(kr, dr, kl, dl, cam.fx, BASELINE_MM)
+    got = ctx.stereo_depth(kr, dr, kl, dl, cam.fx, BASELINE_MM)
+    assert np.array_equal(got[0], ref[0]) and (got[0] >= 0).sum() < 0.05 * len(kr)
+    with pytest.raises(Exception):
+        ctx.stereo_depth(kl, dl, kr, dr, cam.fx, -1.0)
+
+
+def test_pose_from_stereo_depth(ctx, oracle):
+    """Depth planes from the stereo matcher instead of the rendered depth: the pipeline's pose (full detector,
+    ratio test, F-RANSAC, PnP) against the oracle on the same planes and against the rendered motion."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    n_frames = 3
+    scene = synth.Scene(5150, relief=2.0)
+    left = synth.make_sequence(cam, n_frames, 5150, 4, scene=scene)
+    right = synth.make_sequence(cam, n_frames, 5151, 4, scene=scene, baseline_mm=BASELINE_MM)
+    planes = []
+    for f in range(n_frames):
+        kl, dl = ctx.detect_orb(oracle.gray(left["frames"][f]), 2000, 1.2, 8, 20)
+        kr, dr = ctx.detect_orb(oracle.gray(right["frames"][f]), 2000, 1.2, 8, 20)
+        planes.append(ctx.stereo_depth(kl, dl, kr, dr, cam.fx, BASELINE_MM, size=(cam.width, cam.height))[3])
+    planes = np.stack(planes)
+    ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=n_frames, max_features=2000,
+                        camera=K, orb_levels=8)
+    ctx.batch_submit(left["frames"], planes)
+    res = ctx.batch_wait()
+    ref = OracleStream(K, 2000, 20, orb_levels=8, feature_cap=ctx.max_features)
+    for f in range(n_frames):
+        r = ref.process(left["frames"][f], planes[f])
+        assert bool(res["pnp_success"][f]) == r["pnp_success"]
+        if f == 0:
+            continue
+        assert r["pnp_success"] and np.array_equal(ctx.batch_inliers(f), r["inliers"])
+        assert np.abs(res["rvec"][f] - r["rvec"]).max() < 1e-6                                   # rad
+        assert np.abs(res["tvec"][f] - r["tvec"]).max() < 1e-6 * max(1.0, np.linalg.norm(r["tvec"]))
+        R_t, t_t = synth.relative_pose(left["poses"][f - 1], left["poses"][f])
+        # 33 mm of motion seen through depths that carry the 1-px disparity quantisation (about 3 % at 5 m)
+        assert np.linalg.norm(res["tvec"][f] - t_t) < 12.0
+        assert np.abs(oracle.rodrigues(res["rvec"][f]) - R_t).max() < 3e-3

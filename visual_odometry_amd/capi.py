@@ -80,6 +80,8 @@ EXPORTS = {
                                           C.c_int, C.c_double, _P, _P, _P]),
     "vo_undistort": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _P,
                                C.c_int, _P, C.c_int]),
+    "vo_stereo_depth": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_double, C.c_double, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "vo_recover_pose": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                   C.c_double, C.c_int, _P, _P, _P, _P]),
     "vo_image_process": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -228,6 +230,26 @@ class Context:
         self._check(self._lib.vo_undistort(self._h, _ptr(gray), w, h, w, fx, fy, cx, cy, _ptr(d), len(d), _ptr(out),
                                            w))
         return out
+
+    def stereo_depth(self, lk, ld, rk, rd, fx, baseline, band=2.0, min_disp=1.0, max_disp=256.0, ratio=0.8,
+                     size=None):
+        """Band-limited left/right matching with cross-check: (right_idx, disparity, depth[, depth plane])."""
+        lk, rk = np.ascontiguousarray(lk, KP_DTYPE), np.ascontiguousarray(rk, KP_DTYPE)
+        ld, rd = np.ascontiguousarray(ld, np.uint8), np.ascontiguousarray(rd, np.uint8)
+        nl = len(lk)
+        ridx = np.zeros(max(nl, 1), np.int32)
+        disp = np.zeros(max(nl, 1), np.float32)
+        depth = np.zeros(max(nl, 1), np.float32)
+        w, h = size if size is not None else (0, 0)
+        plane = np.zeros((h, w), np.float32) if size is not None else None
+        n = C.c_int(0)
+        self._check(self._lib.vo_stereo_depth(self._h, _ptr(lk), _ptr(ld), nl, _ptr(rk), _ptr(rd), len(rk), fx,
+                                              baseline, band, min_disp, max_disp, ratio, _ptr(ridx), _ptr(disp),
+                                              _ptr(depth), _ptr(plane) if plane is not None else None, w, h,
+                                              C.addressof(n)))
+        out = (ridx[:nl].copy(), disp[:nl].copy(), depth[:nl].copy())
+        assert n.value == int((out[0] >= 0).sum())
+        return out if plane is None else out + (plane,)
 
     def recover_pose(self, E, p1, p2, fx, fy, cx, cy, mask=None, distance_thresh=50.0):
         """cv::recoverPose: (votes, R, t, mask of the winning candidate's votes)."""

@@ -190,6 +190,7 @@ void vo_ctx::release()
 {
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_flat, d_cand_count, d_orb_cand_flat, d_kps, d_desc, d_nkp, d_pattern,
                     d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0, d_orb_tab, d_eq, d_eE, d_eidx, d_enm, d_ecnt, d_einfo, d_emask,
+                    d_st_idx, d_st_disp, d_st_depth, d_st_plane, d_st_n,
                     d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results};
@@ -537,6 +538,79 @@ int vo_match_features_ex(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_d
     HIP_TRY(c, hipMemcpy(info, c->d_info, sizeof(info), hipMemcpyDeviceToHost));
     *n_out = info[3];
     if (info[3] > 0) HIP_TRY(c, hipMemcpy(out, c->d_final, sizeof(vo_match) * info[3], hipMemcpyDefault));
+    return VO_OK;
+}
+
+static bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice;
+}
+
+int vo_stereo_depth(vo_ctx *c, const vo_kp *left_kps, const uint8_t *left_desc, int n_left, const vo_kp *right_kps,
+                    const uint8_t *right_desc, int n_right, double fx, double baseline, float band, float min_disp,
+                    float max_disp, float ratio, int32_t *right_idx, float *disparity, float *depth, float *plane,
+                    int w, int h, int *n_matched)
+{
+    if (!c) return VO_ERR_ARG;
+    if (n_left < 0 || n_right < 0 || n_left > c->cfg.max_features || n_right > c->cfg.max_features ||
+        n_left > 65535 || n_right > 65535 || !(fx > 0) || !(baseline > 0) || !(min_disp > 0) || !(max_disp >= min_disp) ||
+        !(band >= 0) || (plane && (w < 1 || h < 1)))
+        return fail(c, VO_ERR_ARG, "vo_stereo_depth: bad arguments (n_left %d, n_right %d, limit %d)", n_left, n_right,
+                    c->cfg.max_features);
+    if ((n_left && (!left_kps || !left_desc || !right_idx || !disparity || !depth)) ||
+        (n_right && (!right_kps || !right_desc)))
+        return fail(c, VO_ERR_ARG, "vo_stereo_depth: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->d_st_idx) {
+        const size_t n = (size_t)c->cfg.max_features;
+        HIP_TRY(c, hipMalloc(&c->d_st_idx, sizeof(int32_t) * n));
+        HIP_TRY(c, hipMalloc(&c->d_st_disp, sizeof(float) * n));
+        HIP_TRY(c, hipMalloc(&c->d_st_depth, sizeof(float) * n));
+        HIP_TRY(c, hipMalloc(&c->d_st_n, sizeof(int)));
+    }
+    uint32_t *d_plane = nullptr;
+    const size_t plane_px = plane ? (size_t)w * h : 0;
+    if (plane) {
+        if (is_device_pointer(plane)) {
+            d_plane = reinterpret_cast<uint32_t *>(plane);
+        } else {
+            if (plane_px > c->st_plane_cap) {
+                if (c->d_st_plane) (void)hipFree(c->d_st_plane);
+                c->d_st_plane = nullptr; c->st_plane_cap = 0;
+                HIP_TRY(c, hipMalloc(&c->d_st_plane, sizeof(float) * plane_px));
+                c->st_plane_cap = plane_px;
+            }
+            d_plane = reinterpret_cast<uint32_t *>(c->d_st_plane);
+        }
+        HIP_TRY(c, hipMemsetAsync(d_plane, 0xff, sizeof(float) * plane_px, c->stream));  // all NaN
+    }
+    if (n_matched) *n_matched = 0;
+    int rc;
+    if (n_left > 0 && n_right > 0) {
+        if ((rc = upload_features(c, c->op_slot0, left_kps, left_desc, n_left))) return rc;
+        if ((rc = upload_features(c, c->op_slot1, right_kps, right_desc, n_right))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_st_n, 0, sizeof(int), c->stream));
+        launch_stereo_match(c->d_kps + (size_t)c->op_slot0 * c->kp_stride, c->d_desc + (size_t)c->op_slot0 * c->kp_stride * 32,
+                            n_left, c->d_kps + (size_t)c->op_slot1 * c->kp_stride,
+                            c->d_desc + (size_t)c->op_slot1 * c->kp_stride * 32, n_right, band, min_disp, max_disp, ratio,
+                            fx, baseline, kKnnSplits, c->d_partial, c->d_partial_rev, c->d_st_idx, c->d_st_disp,
+                            c->d_st_depth, d_plane, w, h, c->d_st_n, c->stream);
+        if ((rc = finish(c, "vo_stereo_depth"))) return rc;
+        HIP_TRY(c, hipMemcpy(right_idx, c->d_st_idx, sizeof(int32_t) * n_left, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(disparity, c->d_st_disp, sizeof(float) * n_left, hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(depth, c->d_st_depth, sizeof(float) * n_left, hipMemcpyDefault));
+        if (n_matched) HIP_TRY(c, hipMemcpy(n_matched, c->d_st_n, sizeof(int), hipMemcpyDeviceToHost));
+    } else {
+        for (int i = 0; i < n_left; i++) { right_idx[i] = -1; disparity[i] = -1.f; depth[i] = nanf(""); }
+        if ((rc = finish(c, "vo_stereo_depth"))) return rc;
+    }
+    if (plane && d_plane == reinterpret_cast<uint32_t *>(c->d_st_plane))
+        HIP_TRY(c, hipMemcpy(plane, c->d_st_plane, sizeof(float) * plane_px, hipMemcpyDeviceToHost));
     return VO_OK;
 }
 

@@ -62,6 +62,12 @@ struct vo_ctx {
     int e_pts_cap = 0, e_hyp_cap = 0;
     int ensure_essential(int n_points, int n_hyp);
 
+    // stereo operator (allocated on first use)
+    int32_t *d_st_idx = nullptr;
+    float *d_st_disp = nullptr, *d_st_depth = nullptr, *d_st_plane = nullptr;
+    int *d_st_n = nullptr;
+    size_t st_plane_cap = 0;
+
     // pose stage
     float *d_depth = nullptr;  // staging for depth handed over from the host
     int *d_ages = nullptr;     // track ages, one row per feature slot
