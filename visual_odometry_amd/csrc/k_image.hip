@@ -202,6 +202,7 @@ struct FePre {
 struct FeTile {
     int frame, x0, y0;
     bool inside;  // the tile and its apron lie inside the image: no reflection
+    bool fast;    // border tile of an aligned image of at least 8 x 8: branch-free reflection, vector loads
 };
 
 // gray weights split into byte planes for 4-byte dot products:
@@ -227,6 +228,17 @@ __device__ __forceinline__ uint32_t gray_dot_px(uint32_t px, GrayDot g)
     return (lo + (hi << 8)) >> g.shift;
 }
 
+// BORDER_REFLECT_101 for positions at most len - 1 outside [0, len), clamped
+// beyond that: branch-free.  The tile apron reaches 4 px outside the image and
+// the padding of the last tile column/row further, but nothing that is kept
+// depends on pixels more than 3 px outside.
+__device__ __forceinline__ int reflect101_near(int p, int len)
+{
+    p = max(p, -p);
+    p = p >= len ? 2 * len - 2 - p : p;
+    return min(max(p, 0), len - 1);
+}
+
 // issue the global loads of staging task i of a tile (no wait)
 template <int CN>
 __device__ __forceinline__ void fe_issue(FePre<CN> &p, const uint8_t *img, int src_stride, int width, int height,
@@ -234,7 +246,28 @@ __device__ __forceinline__ void fe_issue(FePre<CN> &p, const uint8_t *img, int s
 {
     const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
     const int yb = t.y0 - 4 + tr, xb = t.x0 - 4 + tq * 4;
-    if (t.inside && aligned) {
+    if (t.fast && xb >= 0 && xb + 4 <= width) {
+        // border tile, task inside the image in x: only the row is reflected
+        const uint8_t *row = img + (size_t)reflect101_near(yb, height) * src_stride;
+        if (CN == 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
+            p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
+        } else if (CN == 1) {
+            p.v[0] = *reinterpret_cast<const uint32_t *>(row + xb);
+        } else {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (size_t)xb * 3);
+            p.v[0] = q[0]; p.v[1] = q[1]; p.v[2] = q[2];
+        }
+    } else if (t.fast) {
+        const uint8_t *row = img + (size_t)reflect101_near(yb, height) * src_stride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int xx = reflect101_near(xb + j, width);
+            if (CN == 4) p.v[j] = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
+            else if (CN == 1) p.v[j] = row[xx];
+            else { p.v[3 * j] = row[xx * 3]; p.v[3 * j + 1] = row[xx * 3 + 1]; p.v[3 * j + 2] = row[xx * 3 + 2]; }
+        }
+    } else if (t.inside && aligned) {
         const uint8_t *row = img + (size_t)yb * src_stride;
         if (CN == 4) {
             const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
@@ -335,6 +368,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         tile.y0 = ty * FE_TH;
         tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
                       tile.y0 + FE_GROWS - 4 <= height;
+        tile.fast = !tile.inside && aligned && width >= 8 && height >= 8;
     }
     const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
 
@@ -356,8 +390,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             const int i = tid + u * FE_THREADS;
             if (i < FE_TASKS) {
                 const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
-                *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) =
-                    fe_gray4<CN>(pre[u], tile.inside && aligned, gd);
+                const int xb = x0 - 4 + tq * 4;
+                const bool packed = (tile.inside && aligned) || (tile.fast && xb >= 0 && xb + 4 <= width);
+                *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) = fe_gray4<CN>(pre[u], packed, gd);
             }
         }
     }

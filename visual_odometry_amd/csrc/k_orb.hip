@@ -10,6 +10,8 @@
 // OpenCV's order (the library is built with -ffp-contract=off).
 #include <float.h>
 
+#include <vector>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -20,85 +22,107 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ resize
 
-constexpr int RZ_TW = 128, RZ_TH = 16, RZ_THREADS = 256;
-constexpr int RZ_FP = 272;    // LDS footprint row pitch (bytes): scale <= 2 plus alignment slack
-constexpr int RZ_FROWS = 36;  // footprint rows
-
-// Source bytes p[xo], p[xo + 1] of a staged row as a pair of u16, where the
-// row's dwords r0, r1, r2 start `rel` (0..10) bytes before p[xo].
-__device__ __forceinline__ us2 rz_pick2(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t rel)
-{
-    const uint32_t lo = rel < 4 ? r0 : (rel < 8 ? r1 : r2);
-    const uint32_t hi = rel < 4 ? r1 : (rel < 8 ? r2 : 0u);
-    const uint32_t a = __builtin_amdgcn_alignbyte(hi, lo, rel & 3u);
-    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, a, 0x0c010c00u));
-}
+constexpr int RZ_TW = 128, RZ_TH = 32, RZ_THREADS = 256;
+constexpr int RZ_FP = 288;    // LDS footprint row pitch (bytes): scale <= 2 plus alignment slack
+constexpr int RZ_FROWS = 68;  // footprint rows
+constexpr int RZ_STAGE = (RZ_FROWS * (RZ_FP / 16) + RZ_THREADS - 1) / RZ_THREADS;  // 16-byte staging loads per thread
+constexpr int RZ_SPAN = 6;    // largest source distance between the first and last of a thread's four columns
+static_assert(RZ_TH == kResizeRowPad, "row tables are padded to whole resize tiles");
 
 // Level l from level l-1 for every frame of the batch: cv::resize(...,
 // INTER_LINEAR_EXACT) -- rows in 8.8 fixed point, columns in 16.16,
 // (v + 2^15) >> 16.  xtab/ytab hold per destination column/row the source
 // offset (low 16 bits) and the 8.8 weight of the second tap (high 16 bits),
-// built on the host by orb_axis_table().  One 128x16 output tile per block;
-// the source footprint is staged in LDS with dword loads; a thread computes
-// the same four columns of two rows (three LDS dwords per source row).
+// built on the host by orb_axis_table().  One 128x32 output tile per block;
+// the source footprint is staged in LDS with 16-byte loads.  A thread computes
+// the same four columns of four rows: per source row three LDS dwords are
+// funnel-shifted once so that the first column's left tap sits at byte 0, then
+// one v_perm_b32 with a per-lane selector (set up once per thread) extracts each
+// column's tap pair and one v_dot2_u32_u16 weighs it.
 __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
                                                             int dh, const uint32_t *__restrict__ xtab,
                                                             const uint32_t *__restrict__ ytab)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP + 16];
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * RZ_TW, y0 = blockIdx.y * RZ_TH, f = blockIdx.z;
     // block-uniform footprint (tables are padded to whole tiles with their last entry)
-    const int sx_lo = (int)(xtab[x0] & 0xffffu) & ~3;
+    const int sx_lo = (int)(xtab[x0] & 0xffffu) & ~15;
     const int sx_hi = min((int)(xtab[x0 + RZ_TW - 1] & 0xffffu) + 1, sw - 1);
     const int sy_lo = (int)(ytab[y0] & 0xffffu);
     const int sy_hi = min((int)(ytab[y0 + RZ_TH - 1] & 0xffffu) + 1, sh - 1);
-    const int cols4 = (sx_hi - sx_lo) / 4 + 1, rows = sy_hi - sy_lo + 1;  // host checked: fits the LDS footprint
-    const uint8_t *sp = src.base + f * src.plane_stride;
-    for (int i = tid; i < rows * cols4; i += RZ_THREADS) {
-        const int r = i / cols4, c4 = i - r * cols4;
-        *reinterpret_cast<uint32_t *>(&s_src[r * RZ_FP + c4 * 4]) =
-            *reinterpret_cast<const uint32_t *>(sp + (size_t)(sy_lo + r) * src.pitch + sx_lo + c4 * 4);
+    // 16-byte pieces (planes and their pitch are 128-byte aligned); host checked: fits the LDS footprint
+    const int cols16 = (sx_hi - sx_lo) / 16 + 1, rows = sy_hi - sy_lo + 1;
+    const uint8_t *sp = src.base + f * src.plane_stride + (size_t)sy_lo * src.pitch + sx_lo;
+    {
+        const int n16 = rows * cols16;
+        uint4 piece[RZ_STAGE];
+        int at[RZ_STAGE];
+#pragma unroll
+        for (int u = 0; u < RZ_STAGE; u++) {  // all loads in flight before the first LDS write
+            piece[u] = make_uint4(0, 0, 0, 0);
+            at[u] = 0;
+            if (u * RZ_THREADS < n16) {  // block-uniform; lanes past the end re-read the last piece
+                const int i = min(tid + u * RZ_THREADS, n16 - 1);
+                const int r = i / cols16, c = i - r * cols16;
+                piece[u] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * src.pitch + c * 16);
+                at[u] = r * RZ_FP + c * 16;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RZ_STAGE; u++)
+            if (tid + u * RZ_THREADS < n16) *reinterpret_cast<uint4 *>(&s_src[at[u]]) = piece[u];
     }
     // this thread's four columns
     const int lx = (tid & 31) * 4;
     const uint4 xt = *reinterpret_cast<const uint4 *>(xtab + x0 + lx);
     const uint32_t xe[4] = {xt.x, xt.y, xt.z, xt.w};
-    const uint32_t base = (xe[0] & 0xffffu) & ~3u;  // first staged byte this thread reads
-    uint32_t rel[4];
+    const uint32_t xo0 = xe[0] & 0xffffu;
+    const uint32_t base = xo0 & ~3u, rel0 = xo0 & 3u;  // first staged dword this thread reads, byte of xo0 in it
+    uint32_t sel[4];
     us2 wx[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        rel[j] = (xe[j] & 0xffffu) - base;
+        const uint32_t d = min((xe[j] & 0xffffu) - xo0, (uint32_t)RZ_SPAN);  // host checked: <= RZ_SPAN
+        sel[j] = d * 0x00010001u + 0x0c010c00u;                              // bytes d, d + 1 as two u16
         const uint32_t w1 = xe[j] >> 16;
         wx[j] = __builtin_bit_cast(us2, (256u - w1) | (w1 << 16));
     }
+    uint32_t yes[RZ_TH / 8];  // row table entries of this thread's rows (the table is padded to whole tiles)
+#pragma unroll
+    for (int k = 0; k < RZ_TH / 8; k++) yes[k] = ytab[y0 + (tid >> 5) + k * 8];
     __syncthreads();
 
     uint8_t *dp = dst.base + f * dst.plane_stride;
     const int gx = x0 + lx;
+    if (gx >= dw) return;
+    const uint8_t *col = &s_src[base - sx_lo];
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int ly = (tid >> 5) + half * (RZ_TH / 2), gy = y0 + ly;
-        if (gy >= dh || gx >= dw) continue;
-        const uint32_t ye = ytab[gy];
+    for (int k = 0; k < RZ_TH / 8; k++) {
+        const int gy = y0 + (tid >> 5) + k * 8;
+        if (gy >= dh) continue;
+        const uint32_t ye = yes[k];
         const int yo = (int)(ye & 0xffffu);
         const uint32_t wy1 = ye >> 16;
         const us2 wy = __builtin_bit_cast(us2, (256u - wy1) | (wy1 << 16));
-        const uint32_t *r0 = reinterpret_cast<const uint32_t *>(&s_src[(yo - sy_lo) * RZ_FP + (base - sx_lo)]);
-        const uint32_t *r1 =
-            reinterpret_cast<const uint32_t *>(&s_src[(min(yo + 1, sh - 1) - sy_lo) * RZ_FP + (base - sx_lo)]);
+        const uint32_t *r0 = reinterpret_cast<const uint32_t *>(col + (yo - sy_lo) * RZ_FP);
+        const uint32_t *r1 = reinterpret_cast<const uint32_t *>(col + (min(yo + 1, sh - 1) - sy_lo) * RZ_FP);
         const uint32_t a0 = r0[0], a1 = r0[1], a2 = r0[2], b0 = r1[0], b1 = r1[1], b2 = r1[2];
-        uint32_t out = 0;
+        const uint32_t aL = __builtin_amdgcn_alignbyte(a1, a0, rel0), aH = __builtin_amdgcn_alignbyte(a2, a1, rel0);
+        const uint32_t bL = __builtin_amdgcn_alignbyte(b1, b0, rel0), bH = __builtin_amdgcn_alignbyte(b2, b1, rel0);
+        uint32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t h0 = __builtin_amdgcn_udot2(rz_pick2(a0, a1, a2, rel[j]), wx[j], 0u, false);
-            const uint32_t h1 = __builtin_amdgcn_udot2(rz_pick2(b0, b1, b2, rel[j]), wx[j], 0u, false);
-            const uint32_t v = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, h0 | (h1 << 16)), wy, 32768u, false);
-            out |= (v >> 16) << (8 * j);
+            const uint32_t h0 =
+                __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(aH, aL, sel[j])), wx[j], 0u, false);
+            const uint32_t h1 =
+                __builtin_amdgcn_udot2(__builtin_bit_cast(us2, __builtin_amdgcn_perm(bH, bL, sel[j])), wx[j], 0u, false);
+            v[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, h0 | (h1 << 16)), wy, 32768u, false);
         }
-        *reinterpret_cast<uint32_t *>(dp + (size_t)gy * dst.pitch + gx) = out;  // pitch is padded
+        // results are bits 16..23 of each v (v < 2^24)
+        const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
+        *reinterpret_cast<uint32_t *>(dp + (size_t)gy * dst.pitch + gx) = lo | (hi << 16);  // pitch is padded
     }
 }
 
@@ -493,12 +517,17 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
         L.xtab_off = toff;
         toff += (size_t)L.pitch;
         L.ytab_off = toff;
-        toff += (size_t)((L.h + 15) / 16 * 16);
+        toff += (size_t)((L.h + kResizeRowPad - 1) / kResizeRowPad * kResizeRowPad);
         if (l > 0) {
-            // the resize kernel's LDS footprint of one 128x16 output tile
+            // the resize kernel's LDS footprint of one output tile
             const OrbLevel &S = p.lv[l - 1];
             const double sx = (double)S.w / L.w, sy = (double)S.h / L.h;
-            if (RZ_TW * sx + 8 > RZ_FP || RZ_TH * sy + 3 > RZ_FROWS) return false;
+            if (RZ_TW * sx + 24 > RZ_FP || RZ_TH * sy + 3 > RZ_FROWS) return false;
+            // a thread's four columns must start within RZ_SPAN source pixels of the first
+            std::vector<uint32_t> xt((size_t)L.pitch);
+            orb_axis_table(S.w, L.w, L.pitch, xt.data());
+            for (int x = 0; x + 3 < L.pitch; x += 4)
+                if ((xt[x + 3] & 0xffffu) - (xt[x] & 0xffffu) > (uint32_t)RZ_SPAN) return false;
         }
     }
     p.frame_bytes = off;

@@ -696,7 +696,8 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
         std::vector<uint32_t> tab(p.tab_total, 0u);
         for (int l = 1; l < p.nlevels; l++) {
             orb_axis_table(p.lv[l - 1].w, p.lv[l].w, p.lv[l].pitch, tab.data() + p.lv[l].xtab_off);
-            orb_axis_table(p.lv[l - 1].h, p.lv[l].h, (p.lv[l].h + 15) / 16 * 16, tab.data() + p.lv[l].ytab_off);
+            orb_axis_table(p.lv[l - 1].h, p.lv[l].h, (p.lv[l].h + kResizeRowPad - 1) / kResizeRowPad * kResizeRowPad,
+                           tab.data() + p.lv[l].ytab_off);
         }
         HIP_TRY(ctx, hipMemcpy(d_orb_tab, tab.data(), sizeof(uint32_t) * p.tab_total, hipMemcpyHostToDevice));
     }

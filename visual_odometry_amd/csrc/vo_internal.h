@@ -11,6 +11,7 @@ namespace vo {
 constexpr int kWave = 64;
 constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
 constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
+constexpr int kResizeRowPad = 32;  // rows of a resize tile: the row tables of the pyramid are padded to it
 constexpr int kKnnSplits = 4;      // train-set splits per query block
 constexpr int kFBorder = 31;       // ORB edgeThreshold
 constexpr int kTileW = 128, kTileH = 16;  // tile of the fused image kernel
