@@ -804,10 +804,18 @@ __global__ __launch_bounds__(256) void k_brief(PlaneBatch blur, const vo_kp *__r
         const int x_al = (cx - BR_R) & ~3;  // keypoints are >= 31 px inside the image: never negative
         col0 = cx - x_al;
         const uint8_t *src = blur.base + f * blur.plane_stride + (size_t)(cy - BR_R) * blur.pitch + x_al;
-        for (int i = byte; i < (2 * BR_R + 1) * BR_PWD; i += 32) {
+        // all of a lane's loads are issued before the first LDS write (lanes past the end re-read the last dword)
+        constexpr int N = (2 * BR_R + 1) * BR_PWD, PER = (N + 31) / 32;
+        uint32_t v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = min(byte + 32 * u, N - 1);
             const int r = i / BR_PWD, c = i - r * BR_PWD;
-            s_patch[g][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * blur.pitch + 4 * c);
+            v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * blur.pitch + 4 * c);
         }
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (byte + 32 * u < N) s_patch[g][byte + 32 * u] = v[u];
     }
     __syncthreads();
     if (!live) return;

@@ -434,32 +434,45 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
 {
     __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
+    __shared__ float s_cs[8][2];
     reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
     const int f = blockIdx.y;
     const int g = threadIdx.x >> 5, k = blockIdx.x * 8 + g;
     const int byte = threadIdx.x & 31;
-    const bool live = k < nkp[f];
+    const int n_kp = nkp[f];
+    const bool live = k < n_kp;
+    // double-precision cos / sin of the block's eight angles: one lane each, in a single wave
+    if (threadIdx.x < 8 && blockIdx.x * 8 + (int)threadIdx.x < n_kp) {
+        float angle = kps[(size_t)f * kp_stride + blockIdx.x * 8 + threadIdx.x].angle;
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        s_cs[threadIdx.x][0] = (float)cos((double)angle);
+        s_cs[threadIdx.x][1] = (float)sin((double)angle);
+    }
     int col0 = 0;
-    float a = 1.f, b = 0.f;
     if (live) {
         const vo_kp kp = kps[(size_t)f * kp_stride + k];
         const OrbLevel L = plan.lv[kp.octave];
         const float inv = 1.f / L.scale;
-        float angle = kp.angle;
-        angle *= (float)(3.14159265358979323846 / 180.f);
-        a = (float)cos((double)angle);
-        b = (float)sin((double)angle);
         const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int x_al = (cx - BS_R) & ~3;  // keypoints are >= 31 px inside their level: never negative
         col0 = cx - x_al;
         const uint8_t *src = pyr_blur + (size_t)f * plan.frame_bytes + L.off + (size_t)(cy - BS_R) * L.pitch + x_al;
-        for (int i = byte; i < (2 * BS_R + 1) * BS_PWD; i += 32) {
+        // all of a lane's loads are issued before the first LDS write (lanes past the end re-read the last dword)
+        constexpr int N = (2 * BS_R + 1) * BS_PWD, PER = (N + 31) / 32;
+        uint32_t v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int i = min(byte + 32 * u, N - 1);
             const int r = i / BS_PWD, c = i - r * BS_PWD;
-            s_patch[g][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
+            v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
         }
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (byte + 32 * u < N) s_patch[g][byte + 32 * u] = v[u];
     }
     __syncthreads();
     if (!live) return;
+    const float a = s_cs[g][0], b = s_cs[g][1];
     const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0;
     const int8_t *p = s_pat + byte * 32;
     uint32_t val = 0;
