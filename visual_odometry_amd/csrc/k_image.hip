@@ -131,8 +131,9 @@ constexpr int FE_STAMP_N = 16, FE_STAMP_BLOCKS = 4096, FE_STAMP_FIRST = 40000;
 __device__ unsigned long long g_fe_stamps[FE_STAMP_BLOCKS * FE_STAMP_N];
 #define FE_STAMP(i)                                                                                   \
     do {                                                                                              \
-        if (threadIdx.x == 0 && blockIdx.x >= FE_STAMP_FIRST && blockIdx.x < FE_STAMP_FIRST + FE_STAMP_BLOCKS) \
-            g_fe_stamps[(blockIdx.x - FE_STAMP_FIRST) * FE_STAMP_N + (i)] = __builtin_amdgcn_s_memtime();    \
+        const unsigned lb_ = blockIdx.x + blockIdx.y * gridDim.x;                                     \
+        if (threadIdx.x == 0 && lb_ >= FE_STAMP_FIRST && lb_ < FE_STAMP_FIRST + FE_STAMP_BLOCKS)       \
+            g_fe_stamps[(lb_ - FE_STAMP_FIRST) * FE_STAMP_N + (i)] = __builtin_amdgcn_s_memtime();       \
     } while (0)
 #else
 #define FE_STAMP(i) do { } while (0)
@@ -331,7 +332,8 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
 //      Gaussian's column pass (2-element dot products over row pairs).
 // tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
 //
-// Tile order is XCD-aware: blocks b and b+8 share an XCD (and its L2), so XCD
+// Tile order is XCD-aware: consecutive blocks (grid x fastest) go to consecutive
+// XCDs, so blocks b and b+8 share an XCD (and its L2) and XCD
 // x = b % 8 walks down whole tile columns (frame*tiles_x + tx) congruent to x
 // mod 8; vertically adjacent tiles, which share 8 of their 24 staged rows, are
 // then processed by the same L2 at about the same time.
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          size_t src_frame_stride, PlaneBatch gray_out,
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
-                                                         uint32_t *__restrict__ tile_count, int batch)
+                                                         uint32_t *__restrict__ tile_count, int batch,
+                                                         uint32_t inv_tiles_x)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
@@ -351,19 +354,18 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
-    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
-    const int ncols = batch * tiles_x;
-    const int my_cols = (ncols - xcd + 7) / 8;
-    const int count = my_cols * tiles_y;  // tiles this XCD's blocks share
+    // grid: x = 8 * tile row + XCD slot, y = group of eight tile columns (frame * tiles_x + tx)
+    const int xcd = blockIdx.x & 7;
+    const int col = blockIdx.y * 8 + xcd;
     // rows 16-B (BGRA) / 4-B (gray, BGR) aligned: vector loads allowed
     const bool aligned = CN == 4 ? ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 15) == 0)
                                  : ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 3) == 0);
 
-    if (j0 >= count) return;
+    if (col >= batch * tiles_x) return;
     FeTile tile;
     {
-        const int col = (j0 / tiles_y) * 8 + xcd, ty = j0 - (j0 / tiles_y) * tiles_y;
-        tile.frame = col / tiles_x;
+        const int ty = blockIdx.x >> 3;
+        tile.frame = (int)__umulhi((uint32_t)col, inv_tiles_x);  // col / tiles_x (exact: host-side magic number)
         tile.x0 = (col - tile.frame * tiles_x) * FE_TW;
         tile.y0 = ty * FE_TH;
         tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
@@ -408,13 +410,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     if (want_fast) {
         // ---- 1. pre-test: interior (four pixels per thread) ...
         // bit i of vm: pixel x+i lies where cv::FAST evaluates (3 px inside the image)
-        uint32_t vm = 0;
-        if (y >= 3 && y < height - 3) {
-            const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
-            if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        }
-        uint32_t r01 = 0, r23 = 0;
-        if (vm) {
+        uint32_t r01, r23;
+        {
             const uint32_t up1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 1) * FE_PITCH + gx * 4 + 4]);
             const uint32_t dn1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 7) * FE_PITCH + gx * 4 + 4]);
             const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4]);
@@ -423,8 +420,17 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
             r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
         }
-        const bool pass0 = (r01 & 0xffffu) != 0 && (vm & 1u), pass1 = (r01 >> 16) != 0 && (vm & 2u);
-        const bool pass2 = (r23 & 0xffffu) != 0 && (vm & 4u), pass3 = (r23 >> 16) != 0 && (vm & 8u);
+        if (!tile.inside) {  // block-uniform: border tiles mask the pixels cv::FAST does not evaluate
+            uint32_t vm = 0;
+            if (y >= 3 && y < height - 3) {
+                const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
+                if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            }
+            r01 &= ((vm & 1u) ? 0xffffu : 0u) | ((vm & 2u) ? 0xffff0000u : 0u);
+            r23 &= ((vm & 4u) ? 0xffffu : 0u) | ((vm & 8u) ? 0xffff0000u : 0u);
+        }
+        const bool pass0 = (r01 & 0xffffu) != 0, pass1 = r01 > 0xffffu;
+        const bool pass2 = (r23 & 0xffffu) != 0, pass3 = r23 > 0xffffu;
         // ... and the 1-px rim around the tile (one pixel per thread of the first waves)
         int hr = -1, hc = 0;
         if (tid < FE_HALO_PIX) {
@@ -452,14 +458,19 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&s_qcount, total);
                 base = __builtin_amdgcn_readfirstlane(base);
-                const uint64_t lt = (1ull << lane) - 1ull;
                 const bool pass[4] = {pass0, pass1, pass2, pass3};
+                const uint32_t q0 = (uint32_t)(((gy + 4) << 8) | (4 + 4 * gx));
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    if (pass[i]) s_queue[base + __popcll(m[i] & lt)] = (uint16_t)(((gy + 4) << 8) | (4 + 4 * gx + i));
+                    // base + number of passing lanes below this one
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], base));
+                    if (pass[i]) s_queue[pos] = (uint16_t)(q0 + i);
                     base += (uint32_t)__popcll(m[i]);
                 }
-                if (hr >= 0) s_queue[base + __popcll(m[4] & lt)] = (uint16_t)((hr << 8) | hc);
+                const uint32_t pos =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m[4] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[4], base));
+                if (hr >= 0) s_queue[pos] = (uint16_t)((hr << 8) | hc);
             }
         }
         FE_STAMP(4);
@@ -518,9 +529,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                 if (r >= 4 && r < 4 + FE_TH && cc >= 4 && cc < 4 + FE_TW) {
                     const uint8_t *sp = &s_score[(r - 3) * FE_PITCH + cc];
                     const uint32_t sc = sp[0];
-                    is_max = sc && sc > sp[-FE_PITCH - 1] && sc > sp[-FE_PITCH] && sc > sp[-FE_PITCH + 1] &&
-                             sc > sp[-1] && sc > sp[1] && sc > sp[FE_PITCH - 1] && sc > sp[FE_PITCH] &&
-                             sc > sp[FE_PITCH + 1];
+                    // all eight neighbours at once: no short-circuit branches
+                    const uint32_t n0 = umax3(sp[-FE_PITCH - 1], sp[-FE_PITCH], sp[-FE_PITCH + 1]);
+                    const uint32_t n1 = umax3(sp[FE_PITCH - 1], sp[FE_PITCH], sp[FE_PITCH + 1]);
+                    is_max = sc > umax3(n0, n1, max((uint32_t)sp[-1], (uint32_t)sp[1]));  // implies sc != 0
                     key = ((255u - sc) << 24) | (uint32_t)((y0 - 4 + r) * width + (x0 - 4 + cc));
                 }
             }
@@ -529,7 +541,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&s_ecount, (uint32_t)__popcll(mm));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (is_max) out[base + __popcll(mm & ((1ull << lane) - 1ull))] = key;
+                const uint32_t pos =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, base));
+                if (is_max) out[pos] = key;
             }
         }
         // the wave that arrives last publishes the tile's corner count
@@ -597,19 +611,20 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
 {
     // block b serves XCD group b % 8, which owns the tile columns congruent to
     // b % 8; the grid holds the largest group's tile count for every group
-    const int ncols = ((width + FE_TW - 1) / FE_TW) * batch, tiles_y = (height + FE_TH - 1) / FE_TH;
-    const int blocks = 8 * ((ncols + 7) / 8) * tiles_y;
-    dim3 grid(blocks);
+    const int tiles_x = (width + FE_TW - 1) / FE_TW, ncols = tiles_x * batch, tiles_y = (height + FE_TH - 1) / FE_TH;
+    dim3 grid(8 * tiles_y, (ncols + 7) / 8);
+    // floor(col / tiles_x) == umulhi(col, inv) for col * tiles_x < 2^32
+    const uint32_t inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
 }
 
 // ---------------------------------------------------------------- select
