@@ -349,7 +349,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint32_t s_hpair[FE_HPAIRS * FE_TW];  // row sums of rows (2p, 2p+1)
-    __shared__ uint16_t s_queue[FE_QCAP];
+    __shared__ uint16_t s_queue[FE_QCAP + 64];  // + one spare slot per lane for the unconditional stores
     __shared__ uint32_t s_qcount, s_ecount, s_done;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -434,10 +434,11 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         // ... and the 1-px rim around the tile (one pixel per thread of the first waves)
         int hr = -1, hc = 0;
         if (tid < FE_HALO_PIX) {
-            if (tid < FE_TW + 2) { hr = 3; hc = 3 + tid; }
-            else if (tid < 2 * (FE_TW + 2)) { hr = 4 + FE_TH; hc = 3 + tid - (FE_TW + 2); }
-            else if (tid < 2 * (FE_TW + 2) + FE_TH) { hr = 4 + tid - 2 * (FE_TW + 2); hc = 3; }
-            else { hr = 4 + tid - 2 * (FE_TW + 2) - FE_TH; hc = 4 + FE_TW; }
+            // top row, bottom row, left column, right column of the rim (selects, no branches)
+            const bool top = tid < FE_TW + 2, horiz = tid < 2 * (FE_TW + 2), left = tid < 2 * (FE_TW + 2) + FE_TH;
+            const int side = tid - 2 * (FE_TW + 2) - (left ? 0 : FE_TH);
+            hr = horiz ? (top ? 3 : 4 + FE_TH) : 4 + side;
+            hc = horiz ? 3 + tid - (top ? 0 : FE_TW + 2) : (left ? 3 : 4 + FE_TW);
             const int ix = x0 - 4 + hc, iy = y0 - 4 + hr;
             bool ok = ix >= 3 && ix < width - 3 && iy >= 3 && iy < height - 3;
             if (ok) {
@@ -465,12 +466,13 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                     // base + number of passing lanes below this one
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
                         (uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], base));
-                    if (pass[i]) s_queue[pos] = (uint16_t)(q0 + i);
+                    // unconditional store: lanes that did not pass write their own spare slot past the queue
+                    s_queue[pass[i] ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)(q0 + i);
                     base += (uint32_t)__popcll(m[i]);
                 }
                 const uint32_t pos =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(m[4] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[4], base));
-                if (hr >= 0) s_queue[pos] = (uint16_t)((hr << 8) | hc);
+                s_queue[hr >= 0 ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)((hr << 8) | hc);
             }
         }
         FE_STAMP(4);
@@ -497,7 +499,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     // ---- Gaussian, row pass: row sums of tile rows 1 .. 22, two rows per task, taken by the last
     // threads of the block so that the waves without queue entries do it
     if (blur.base) {
-        for (int t = FE_THREADS - 1 - tid; t < FE_HPAIRS * 32; t += FE_THREADS) {
+        static_assert(FE_HPAIRS * 32 <= FE_THREADS, "one row-pair task per thread at most");
+        const int t = FE_THREADS - 1 - tid;
+        if (t < FE_HPAIRS * 32) {
             const int hp = t >> 5, tg = t & 31;
             const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 1) * FE_PITCH + tg * 4]);
             const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 2) * FE_PITCH + tg * 4]);
