@@ -125,6 +125,21 @@ __device__ __forceinline__ bool fast_quick(uint32_t v, uint32_t p0, uint32_t p8,
     return b || d;
 }
 
+#ifdef VO_FE_CUT
+// Diagnostic build only: the kernel ends after barrier VO_FE_CUT with an empty
+// corner list, so that hardware counters can be attributed to its phases.
+#define FE_CUT(n)                                                                                          \
+    do {                                                                                                   \
+        if (VO_FE_CUT == (n)) {                                                                            \
+            if (cand && threadIdx.x == 0)                                                                  \
+                tile_count[(size_t)tile.frame * tiles_x * tiles_y + (tile.y0 / FE_TH) * tiles_x + tile.x0 / FE_TW] = 0; \
+            return;                                                                                        \
+        }                                                                                                  \
+    } while (0)
+#else
+#define FE_CUT(n) do { } while (0)
+#endif
+
 #ifdef VO_FE_STAMPS
 // Diagnostic build only: cycle stamps of wave 0 of a window of blocks.
 constexpr int FE_STAMP_N = 16, FE_STAMP_BLOCKS = 4096, FE_STAMP_FIRST = 40000;
@@ -401,6 +416,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(2);
     __syncthreads();
     FE_STAMP(3);
+    FE_CUT(1);
 
     const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
     const int x = x0 + gx * 4, y = y0 + gy;  // image position of the first of them
@@ -478,6 +494,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         FE_STAMP(4);
         __syncthreads();
         FE_STAMP(5);
+        FE_CUT(2);
 
         // ---- 2. full score of the queued pixels (the first waves)
         qn = (int)s_qcount;
@@ -517,6 +534,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(6);
     __syncthreads();
     FE_STAMP(7);
+    FE_CUT(3);
 
     // ---- 3. non-max suppression of the queued corners (score row sr <-> tile row sr + 3), direct emission
     if (cand) {

@@ -196,7 +196,9 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __shared__ int s_cut, s_n1, s_n2, s_remaining;
     __shared__ uint32_t s_prefix;
 
-    const int l = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    // grid x = frame, y = level: consecutive blocks go to consecutive XCDs, so every XCD sees all levels
+    // (with the level in x each XCD would serve a single level and the level-0 one would finish last)
+    const int f = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
     // the level's corners as one list (s_buf is free until the gather below)
@@ -587,7 +589,7 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
                        const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
                        hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orb_select, dim3(plan.nlevels, batch), dim3(OS_THREADS), 0, s, plan, batch, pyr, cand,
+    hipLaunchKernelGGL(k_orb_select, dim3(batch, plan.nlevels), dim3(OS_THREADS), 0, s, plan, batch, pyr, cand,
                        tile_count, flat, lvl_ras, lvl_resp, lvl_n);
 }
 
