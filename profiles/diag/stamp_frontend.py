@@ -62,3 +62,18 @@ q = pn[:, 11:15].astype(np.int64)
 for i, n in enumerate(["  EPnP: control points + barycentric", "  EPnP: 10x12 singular vectors (16 lanes)",
                        "  EPnP: betas, Gauss-Newton, R|t (3 lanes)"]):
     print(f"{n:44s} median {np.median(q[:, i + 1] - q[:, i]):9.0f} cycles")
+
+# ---- F-RANSAC kernel (one block per frame pair): thread 0 of the first 256 blocks, last round of the loop
+fr = np.zeros((256, 16), np.uint64)
+raw.vo_debug_fr_stamps.argtypes = [C.c_void_p]
+assert raw.vo_debug_fr_stamps(fr.ctypes.data) == 0
+t = fr[:, :10].astype(np.int64)
+ok = t[:, 9] > 0
+t = t[ok]
+names = ["load points", "(earlier rounds)", "rng window", "subset attempts", "chain (one lane)", "7-point solve",
+         "score", "accept (one lane)", "final mask + compaction"]
+d = np.diff(t, axis=1)
+print("F-RANSAC blocks with stamps:", int(ok.sum()), " iterations run:", res_iters if "res_iters" in dir() else "")
+for i, n in enumerate(names):
+    print(f"{n:36s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
+print(f"{'whole kernel':36s} median {np.median(t[:, 9] - t[:, 0]):9.0f}")

@@ -25,6 +25,7 @@ namespace vo {
 
 constexpr int FR_THREADS = 512;
 constexpr int FR_CHUNK = 64;
+constexpr int FR_FIRST = 8;  // iterations of the first round
 constexpr int FR_WIN = FR_CHUNK * 7 + 192;
 constexpr int FR_MAX_ATTEMPTS = 10000;
 
@@ -277,6 +278,23 @@ __device__ int ransac_update_num_iters(double p, double ep, int model_points, in
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 
+#ifdef VO_FE_STAMPS
+// Diagnostic build only: cycle stamps of thread 0 of the first 256 blocks
+// (the stamps of the RANSAC loop are those of the last round).
+__device__ unsigned long long g_fr_stamps[256 * 16];
+#define FR_STAMP(i)                                                                      \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256)                                        \
+            g_fr_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();           \
+    } while (0)
+extern "C" int vo_debug_fr_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_stamps), sizeof(unsigned long long) * 256 * 16);
+}
+#else
+#define FR_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restrict__ good,
                                                          const int *__restrict__ n_good, int kp_stride,
                                                          const uint32_t *__restrict__ rng_raw, int rng_len,
@@ -288,6 +306,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
     FrShared &S = *reinterpret_cast<FrShared *>(s_dyn);
     float4 *pts = reinterpret_cast<float4 *>(s_dyn + ((sizeof(FrShared) + 15) & ~size_t(15)));
 
+    FR_STAMP(0);
     const int pair = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(n_good[pair], kp_stride);
@@ -318,8 +337,10 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
     __syncthreads();
 
     const float thr2 = (float)(prm.threshold * prm.threshold);
+    FR_STAMP(1);
 
     while (true) {
+        FR_STAMP(2);
         // 1. window of draws
         const long long pos = S.pos;
         for (int k = tid; k < FR_WIN; k += FR_THREADS) {
@@ -328,6 +349,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             if (a >= rng_len) S.cons[k] = 0;
         }
         __syncthreads();
+        FR_STAMP(3);
         // 2. one subset attempt per window offset
         for (int o = tid; o < FR_WIN; o += FR_THREADS) {
             int idx[7];
@@ -346,10 +368,13 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             S.valid[o] = (uint8_t)ok;
         }
         __syncthreads();
+        FR_STAMP(4);
         // 3. chain offsets into iterations
         if (tid == 0) {
             int w = 0, nc = 0, att = S.attempts;
-            const int want = min(FR_CHUNK, S.niters - S.iter);
+            // The first round is short: on a typical frame pair the first model or two already explain most
+            // matches and the adaptive iteration count drops below it; later rounds take what is still needed.
+            const int want = min(S.iter == 0 && !lmeds ? FR_FIRST : FR_CHUNK, S.niters - S.iter);
             bool stuck = false;
             while (nc < want && !stuck) {
                 for (;;) {
@@ -365,6 +390,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             if (nc == 0 && w == 0) S.failed = 1;  // RNG table exhausted: cannot progress
         }
         __syncthreads();
+        FR_STAMP(5);
         const int nc = S.nchunk;
         // 4. solve
         if (tid < nc) {
@@ -378,6 +404,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             S.nmodels[tid] = solve_f7(a, b, S.models[tid]);
         }
         __syncthreads();
+        FR_STAMP(6);
         // 5. score every candidate matrix: one wave per (iteration, model)
         for (int hm = wave; hm < nc * 3; hm += FR_THREADS / kWave) {
             const int h = hm / 3, m = hm - 3 * h;
@@ -401,6 +428,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             if (lane == 0) S.counts[h][m] = cnt;
         }
         __syncthreads();
+        FR_STAMP(7);
         // 6. sequential acceptance
         if (tid == 0) {
             for (int h = 0; h < nc; h++) {
@@ -428,6 +456,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             if (S.failed) S.done = 1;  // getSubset gave up: stop (iter == 0 -> nothing found)
         }
         __syncthreads();
+        FR_STAMP(8);
         if (S.done) break;
     }
 
@@ -483,6 +512,7 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
         double *Fo = Fout + (size_t)pair * 9;
         for (int i = 0; i < 9; i++) Fo[i] = found ? S.best[i] : 0.0;
     }
+    FR_STAMP(9);
 }
 
 void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride, const uint32_t *rng_raw,
