@@ -14,6 +14,14 @@ constexpr int KNN_TILE = 128;                        // train descriptors per LD
 // key = (distance << 16) | train index: the order is (distance, then lower
 // train index), the order in which cv::BFMatcher::knnMatch reports equal
 // distances (reference src/feature_matcher.cpp:27-31).
+// median of three unsigned values (v_med3_u32; the compiler has no builtin for the integer form)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
                                                       const int *__restrict__ nkp,
                                                       const int *__restrict__ q_slot,
@@ -64,9 +72,9 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
                 d += __popc(qb[i].z ^ tb.z);
                 d += __popc(qb[i].w ^ tb.w);
                 const uint32_t key = (d << 16) | jj;
-                const uint32_t n0 = min(k0[i], key);
-                k1[i] = min(k1[i], max(k0[i], key));
-                k0[i] = n0;
+                // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
+                k1[i] = umed3(k0[i], k1[i], key);
+                k0[i] = min(k0[i], key);
             }
         }
     }
