@@ -14,6 +14,15 @@ constexpr int KNN_TILE = 128;                        // train descriptors per LD
 // key = (distance << 16) | train index: the order is (distance, then lower
 // train index), the order in which cv::BFMatcher::knnMatch reports equal
 // distances (reference src/feature_matcher.cpp:27-31).
+// popcount(x) + acc in one instruction (v_bcnt_u32_b32); written out because the compiler otherwise
+// computes independent popcounts and adds them up with extra instructions
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // median of three unsigned values (v_med3_u32; the compiler has no builtin for the integer form)
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -31,8 +40,9 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint4 s_tile[KNN_TILE * 2];
 
     const int pair = blockIdx.z, split = blockIdx.y;
-    const int qs = q_slot[pair], ts = t_slot[pair];
-    const int nq = nkp[qs], nt = nkp[ts];
+    // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
+    const int qs = __builtin_amdgcn_readfirstlane(q_slot[pair]), ts = __builtin_amdgcn_readfirstlane(t_slot[pair]);
+    const int nq = __builtin_amdgcn_readfirstlane(nkp[qs]), nt = __builtin_amdgcn_readfirstlane(nkp[ts]);
     const int qbase = blockIdx.x * KNN_QPB;
     if (qbase >= nq) return;
 
@@ -58,25 +68,31 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         __syncthreads();
         for (int i = threadIdx.x; i < jn * 2; i += KNN_THREADS) s_tile[i] = td[2 * j0 + i];
         __syncthreads();
-        for (int j = 0; j < jn; j++) {
+        auto one = [&](int j) {
             const uint4 ta = s_tile[2 * j], tb = s_tile[2 * j + 1];  // wave-uniform: LDS broadcast
             const uint32_t jj = (uint32_t)(j0 + j);
 #pragma unroll
             for (int i = 0; i < KNN_QPL; i++) {
-                uint32_t d = __popc(qa[i].x ^ ta.x);
-                d += __popc(qa[i].y ^ ta.y);
-                d += __popc(qa[i].z ^ ta.z);
-                d += __popc(qa[i].w ^ ta.w);
-                d += __popc(qb[i].x ^ tb.x);
-                d += __popc(qb[i].y ^ tb.y);
-                d += __popc(qb[i].z ^ tb.z);
-                d += __popc(qb[i].w ^ tb.w);
+                // eight XOR + eight accumulating popcounts (the accumulation is chained on purpose)
+                uint32_t d = popc_acc(qa[i].x ^ ta.x, 0u);
+                d = popc_acc(qa[i].y ^ ta.y, d);
+                d = popc_acc(qa[i].z ^ ta.z, d);
+                d = popc_acc(qa[i].w ^ ta.w, d);
+                d = popc_acc(qb[i].x ^ tb.x, d);
+                d = popc_acc(qb[i].y ^ tb.y, d);
+                d = popc_acc(qb[i].z ^ tb.z, d);
+                d = popc_acc(qb[i].w ^ tb.w, d);
                 const uint32_t key = (d << 16) | jj;
                 // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
                 k1[i] = umed3(k0[i], k1[i], key);
                 k0[i] = min(k0[i], key);
             }
+        };
+        int j = 0;
+        for (; j + 4 <= jn; j += 4) {
+            one(j); one(j + 1); one(j + 2); one(j + 3);
         }
+        for (; j < jn; j++) one(j);
     }
 
 #pragma unroll
