@@ -255,55 +255,57 @@ __device__ __forceinline__ int reflect101_near(int p, int len)
     return min(max(p, 0), len - 1);
 }
 
-// issue the global loads of staging task i of a tile (no wait)
+// How a tile is staged: FE_INSIDE -- tile and apron inside an aligned image, plain vector loads;
+// FE_BORDER -- border tile of an aligned image of at least 8 x 8, branch-free reflection;
+// FE_GENERAL -- anything else (unaligned rows, tiny images): per-pixel loads, iterated reflection.
+enum { FE_INSIDE = 0, FE_BORDER = 1, FE_GENERAL = 2 };
+
 template <int CN>
-__device__ __forceinline__ void fe_issue(FePre<CN> &p, const uint8_t *img, int src_stride, int width, int height,
-                                         const FeTile &t, int i, bool aligned)
+__device__ __forceinline__ void fe_load_packed(FePre<CN> &p, const uint8_t *row, int xb)
 {
-    const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
-    const int yb = t.y0 - 4 + tr, xb = t.x0 - 4 + tq * 4;
-    if (t.fast && xb >= 0 && xb + 4 <= width) {
-        // border tile, task inside the image in x: only the row is reflected
-        const uint8_t *row = img + (size_t)reflect101_near(yb, height) * src_stride;
-        if (CN == 4) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
-            p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
-        } else if (CN == 1) {
-            p.v[0] = *reinterpret_cast<const uint32_t *>(row + xb);
-        } else {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (size_t)xb * 3);
-            p.v[0] = q[0]; p.v[1] = q[1]; p.v[2] = q[2];
-        }
-    } else if (t.fast) {
-        const uint8_t *row = img + (size_t)reflect101_near(yb, height) * src_stride;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int xx = reflect101_near(xb + j, width);
-            if (CN == 4) p.v[j] = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
-            else if (CN == 1) p.v[j] = row[xx];
-            else { p.v[3 * j] = row[xx * 3]; p.v[3 * j + 1] = row[xx * 3 + 1]; p.v[3 * j + 2] = row[xx * 3 + 2]; }
-        }
-    } else if (t.inside && aligned) {
-        const uint8_t *row = img + (size_t)yb * src_stride;
-        if (CN == 4) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
-            p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
-        } else if (CN == 1) {
-            p.v[0] = *reinterpret_cast<const uint32_t *>(row + xb);
-        } else {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (size_t)xb * 3);
-            p.v[0] = q[0]; p.v[1] = q[1]; p.v[2] = q[2];
-        }
+    if (CN == 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)xb * 4);
+        p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
+    } else if (CN == 1) {
+        p.v[0] = *reinterpret_cast<const uint32_t *>(row + xb);
     } else {
-        const uint8_t *row = img + (size_t)reflect101(yb, height) * src_stride;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int xx = reflect101(xb + j, width);
-            if (CN == 4) p.v[j] = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
-            else if (CN == 1) p.v[j] = row[xx];
-            else { p.v[3 * j] = row[xx * 3]; p.v[3 * j + 1] = row[xx * 3 + 1]; p.v[3 * j + 2] = row[xx * 3 + 2]; }
-        }
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(row + (size_t)xb * 3);
+        p.v[0] = q[0]; p.v[1] = q[1]; p.v[2] = q[2];
     }
+}
+
+template <int CN>
+__device__ __forceinline__ void fe_load_pixel(FePre<CN> &p, const uint8_t *row, int j, int xx)
+{
+    if (CN == 4) p.v[j] = *reinterpret_cast<const uint32_t *>(row + (size_t)xx * 4);
+    else if (CN == 1) p.v[j] = row[xx];
+    else { p.v[3 * j] = row[xx * 3]; p.v[3 * j + 1] = row[xx * 3 + 1]; p.v[3 * j + 2] = row[xx * 3 + 2]; }
+}
+
+// issue the global loads of staging task (tr, tq) of a tile (no wait); returns whether the pixels arrive packed
+template <int CN, int PATH>
+__device__ __forceinline__ bool fe_issue(FePre<CN> &p, const uint8_t *img, int src_stride, int width, int height,
+                                         const FeTile &t, int tr, int tq)
+{
+    const int yb = t.y0 - 4 + tr, xb = t.x0 - 4 + tq * 4;
+    if (PATH == FE_INSIDE) {
+        fe_load_packed<CN>(p, img + (size_t)yb * src_stride, xb);
+        return true;
+    }
+    if (PATH == FE_BORDER) {
+        const uint8_t *row = img + (size_t)reflect101_near(yb, height) * src_stride;
+        if (xb >= 0 && xb + 4 <= width) {  // inside the image in x: only the row is reflected
+            fe_load_packed<CN>(p, row, xb);
+            return true;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) fe_load_pixel<CN>(p, row, j, reflect101_near(xb + j, width));
+        return false;
+    }
+    const uint8_t *row = img + (size_t)reflect101(yb, height) * src_stride;
+#pragma unroll
+    for (int j = 0; j < 4; j++) fe_load_pixel<CN>(p, row, j, reflect101(xb + j, width));
+    return false;
 }
 
 // four gray bytes of a loaded task
@@ -328,6 +330,34 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
             out |= gray_dot_px(p.v[3 * j] | (p.v[3 * j + 1] << 8) | (p.v[3 * j + 2] << 16), g) << (8 * j);
     }
     return out;
+}
+
+// Stage the tile and its apron as 8-bit gray in LDS (all global loads of a thread are issued before the first
+// use) and clear the score tile and the block's counters.
+template <int CN, int PATH>
+__device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint32_t *s_counters, const uint8_t *img,
+                                         int src_stride, int width, int height, const FeTile &tile, GrayCoeffs c)
+{
+    const int tid = threadIdx.x;
+    FePre<CN> pre[FE_TPT];
+    bool packed[FE_TPT];
+    int at[FE_TPT];
+    const GrayDot gd = gray_dot(c);
+#pragma unroll
+    for (int u = 0; u < FE_TPT; u++) {
+        const int i = tid + u * FE_THREADS;
+        packed[u] = false;
+        const int tr = i / (FE_PITCH / 4), tq = i - tr * (FE_PITCH / 4);
+        at[u] = tr * FE_PITCH + tq * 4;
+        if (i < FE_TASKS) packed[u] = fe_issue<CN, PATH>(pre[u], img, src_stride, width, height, tile, tr, tq);
+    }
+    for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
+    if (tid < 3) s_counters[tid] = 0;
+    FE_STAMP(1);
+#pragma unroll
+    for (int u = 0; u < FE_TPT; u++)
+        if (tid + u * FE_THREADS < FE_TASKS)
+            *reinterpret_cast<uint32_t *>(&s_gray[at[u]]) = fe_gray4<CN>(pre[u], packed[u], gd);
 }
 
 // One block = one 128x16 tile of one frame:
@@ -365,7 +395,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint32_t s_hpair[FE_HPAIRS * FE_TW];  // row sums of rows (2p, 2p+1)
     __shared__ uint16_t s_queue[FE_QCAP + 64];  // + one spare slot per lane for the unconditional stores
-    __shared__ uint32_t s_qcount, s_ecount, s_done;
+    __shared__ uint32_t s_counters[3];  // queue entries, emitted corners, waves done
+    uint32_t &s_qcount = s_counters[0], &s_ecount = s_counters[1], &s_done = s_counters[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
@@ -390,28 +421,15 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
 
     FE_STAMP(0);
-    // ---- 0. stage: all global loads of the thread are issued before the first use
+    // ---- 0. stage
     {
-        FePre<CN> pre[FE_TPT];
         const uint8_t *img = src + f * src_frame_stride;
-        const GrayDot gd = gray_dot(c);
-#pragma unroll
-        for (int u = 0; u < FE_TPT; u++)
-            if (tid + u * FE_THREADS < FE_TASKS)
-                fe_issue<CN>(pre[u], img, src_stride, width, height, tile, tid + u * FE_THREADS, aligned);
-        for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
-        if (tid == 0) { s_qcount = 0; s_ecount = 0; s_done = 0; }
-        FE_STAMP(1);
-#pragma unroll
-        for (int u = 0; u < FE_TPT; u++) {
-            const int i = tid + u * FE_THREADS;
-            if (i < FE_TASKS) {
-                const int tr = i / (FE_PITCH / 4), tq = i % (FE_PITCH / 4);
-                const int xb = x0 - 4 + tq * 4;
-                const bool packed = (tile.inside && aligned) || (tile.fast && xb >= 0 && xb + 4 <= width);
-                *reinterpret_cast<uint32_t *>(&s_gray[tr * FE_PITCH + tq * 4]) = fe_gray4<CN>(pre[u], packed, gd);
-            }
-        }
+        if (tile.inside && aligned)
+            fe_stage<CN, FE_INSIDE>(s_gray, s_score, s_counters, img, src_stride, width, height, tile, c);
+        else if (tile.fast)
+            fe_stage<CN, FE_BORDER>(s_gray, s_score, s_counters, img, src_stride, width, height, tile, c);
+        else
+            fe_stage<CN, FE_GENERAL>(s_gray, s_score, s_counters, img, src_stride, width, height, tile, c);
     }
     FE_STAMP(2);
     __syncthreads();
