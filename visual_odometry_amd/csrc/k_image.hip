@@ -102,12 +102,22 @@ __device__ __forceinline__ uint32_t fast_score(const uint32_t (&p)[16], uint32_t
         mx3[k] = umax3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
         mn3[k] = umin3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
     }
-    uint32_t lo = 255u, hi = 0u;  // min over arcs of max; max over arcs of min
+    // per arc of 9: max / min of its three triples; then the min over arcs of the max and the max over arcs of
+    // the min, reduced three at a time
+    uint32_t mx9[16], mn9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo = min(lo, umax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
-        hi = max(hi, umin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+        mx9[k] = umax3(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+        mn9[k] = umin3(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
     }
+    uint32_t tl[5], th[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        tl[k] = umin3(mx9[3 * k], mx9[3 * k + 1], mx9[3 * k + 2]);
+        th[k] = umax3(mn9[3 * k], mn9[3 * k + 1], mn9[3 * k + 2]);
+    }
+    const uint32_t lo = umin3(umin3(tl[0], tl[1], tl[2]), umin3(tl[3], tl[4], mx9[15]), 255u);
+    const uint32_t hi = umax3(umax3(th[0], th[1], th[2]), umax3(th[3], th[4], mn9[15]), 0u);
     const int a = (int)v - (int)lo, b = (int)hi - (int)v;
     const int sc = max(a, b) - 1;
     return sc >= thr ? (uint32_t)sc : 0u;
