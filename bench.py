@@ -186,11 +186,23 @@ def main():
             bound, amount, peak, unit = work[dominant]
             ach = amount / (acc[dominant] * 1e-3)
             roof.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
+        # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
+        # process): used only when they were taken at this launch size; null where the counter is uncalibrated
+        measured = {}
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("frames_per_launch") == Bc:
+                measured = {k: v.get("bytes") for k, v in tj["stages"].items()}
+        roof["traffic"] = measured.get(dominant)
         stage_roof = {}
         for k, (bound, amount, peak, unit) in work.items():
             if acc.get(k, 0.0) > 1e-4 and amount > 0:
                 a_ = amount / (acc[k] * 1e-3)
                 stage_roof[k] = {"bound": bound, "achieved": a_, "peak": peak, "unit": unit, "frac": a_ / peak}
+                if bound == "hbm":
+                    stage_roof[k]["algorithmic_bytes"] = amount * 1e9
+                    stage_roof[k]["traffic"] = measured.get(k)
         out = {
             "metric": "frames/sec (detect+match+RANSAC pose) @1280x720, 2000 kp",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

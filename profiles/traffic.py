@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of the image stages from a FETCH_SIZE / WRITE_SIZE summary (pmcstats.py output of the two
+--pmc passes of `python3 bench.py --cpu-frames 0 --steps 3 --warmup 1`): writes the JSON bench.py reads for
+`roofline.traffic`.  FETCH_SIZE is doubled for the kernels whose loads are 16 bytes per lane (the level-0 tile
+kernel on BGRA input, the resize kernel), as the counter tallies 128-byte requests at 64 bytes on gfx950; kernels
+with narrower loads are left uncalibrated (bytes = null, raw counters kept)."""
+import json
+import sys
+
+
+def main(path, frames_per_launch, out):
+    kb = {}
+    for line in open(path):
+        parts = line.split()
+        if len(parts) < 3 or "=" not in parts[-1]:
+            continue
+        name, n = parts[0], int(parts[1])
+        k, v = parts[-1].split("=")
+        kb.setdefault(name, {})[k] = (float(v), n)
+
+    def find(frag):
+        for name, d in kb.items():
+            if frag in name:
+                return d
+        return None
+
+    stages = {}
+    d = find("k_frontendILi4E")
+    if d:
+        stages["frontend_fast_nms_blur"] = {
+            "bytes": (2 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024,
+            "note": "2 x FETCH_SIZE (16-byte loads) + WRITE_SIZE, one launch"}
+    d = find("k_resize_exact")
+    if d:
+        n = d["FETCH_SIZE"][1] // max(1, find("k_frontendILi4E")["FETCH_SIZE"][1])  # launches per batch
+        stages["pyramid_resize"] = {
+            "bytes": (2 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024 * n,
+            "note": f"{n} launches; 2 x FETCH_SIZE (16-byte loads) + WRITE_SIZE"}
+    d = find("k_frontendILi1E")
+    if d:
+        n = d["FETCH_SIZE"][1] // max(1, find("k_frontendILi4E")["FETCH_SIZE"][1])
+        stages["frontend_upper_levels"] = {
+            "bytes": None, "raw_fetch_bytes": d["FETCH_SIZE"][0] * 1024 * n, "write_bytes": d["WRITE_SIZE"][0] * 1024 * n,
+            "note": f"{n} launches; 4-byte loads: FETCH_SIZE is uncalibrated for this width, raw value kept"}
+    json.dump({"frames_per_launch": frames_per_launch, "source": path, "stages": stages}, open(out, "w"), indent=1)
+    print(json.dumps(stages, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3])

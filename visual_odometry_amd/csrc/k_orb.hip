@@ -387,21 +387,29 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
     const size_t o = ((size_t)f * plan.nlevels + lv) * kOrbLevelCap + (live ? j : 0);
     const uint32_t ras = live ? lvl_ras[o] : (uint32_t)(15 * Lw + 15);
     const int y = ras / (uint32_t)Lw, x = ras - y * Lw;
-    const uint8_t *center = pyr + (size_t)f * plan.frame_bytes + Loff + (size_t)y * Lpitch + x;
+    // block-uniform base + 32-bit offsets (a frame's pyramid is far below 4 GB): one add per row
+    const uint8_t *frame = pyr + (size_t)f * plan.frame_bytes;
 
     const int u = min(gl - 15, 15);  // lane 31 of the group repeats column 15 and is masked below
     const int au = gl == 31 ? 16 : abs(u);
+    uint32_t off = (uint32_t)Loff + (uint32_t)(y - 15) * (uint32_t)Lpitch + (uint32_t)(x + u);
     int val[31];
 #pragma unroll
-    for (int k = 0; k < 31; k++) val[k] = center[(k - 15) * Lpitch + u];
-    int m10 = 0, m01 = 0;
-#pragma unroll
     for (int k = 0; k < 31; k++) {
-        const int v = k - 15;
-        const int xk = au <= kUmaxC(v < 0 ? -v : v) ? val[k] : 0;
-        m10 += u * xk;
-        m01 += v * xk;
+        val[k] = frame[off];
+        off += (uint32_t)Lpitch;
     }
+    // m10 = sum u * I, m01 = sum v * I over the disc: rows +v and -v share their half-width, so each pair is
+    // masked once, with its sum feeding m10 (times u at the end) and its difference m01
+    int sum = au <= kUmaxC(0) ? val[15] : 0, m01 = 0;
+#pragma unroll
+    for (int v = 1; v <= 15; v++) {
+        const bool in = au <= kUmaxC(v);
+        const int a = val[15 + v], b = val[15 - v];
+        sum += in ? a + b : 0;
+        m01 += v * (in ? a - b : 0);
+    }
+    int m10 = u * sum;
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) {
         m10 += __shfl_xor(m10, off);
