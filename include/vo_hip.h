@@ -336,6 +336,29 @@ int vo_batch_set_previous(vo_ctx *ctx, int stream, const vo_kp *kps,
 int vo_batch_submit(vo_ctx *ctx, const uint8_t *frames, int row_stride,
                     size_t frame_stride, const float *depth,
                     int depth_row_stride, size_t depth_frame_stride);
+/* Parameters of the stereo matcher (see vo_stereo_depth). */
+typedef struct {
+    double baseline;      /* distance between the cameras, in the unit the depth is wanted in (mm for the pose stage) */
+    float band;           /* largest |yL - yR| of a candidate pair, pixels */
+    float min_disparity;  /* > 0 */
+    float max_disparity;
+    float ratio;          /* Lowe ratio against the second candidate (>= 1 disables the test) */
+} vo_stereo_cfg;
+/* Stereo variant of vo_batch_submit for rigs without a depth sensor: `right`
+ * holds the right image of every frame of the batch (same layout as `left`).
+ * Both images go through the configured detector, vo_stereo_depth's matcher
+ * runs for every frame on the device, and the sparse depth planes it produces
+ * take the place of the `depth` argument of vo_batch_submit; everything after
+ * that is the same pipeline (the reference reads its depth plane from the ZED
+ * SDK, src/zed_interface.cpp:84-85, src/frame_processor.cpp:230-308).  The
+ * context must have been created with max_batch >= 2 * batch. */
+int vo_batch_submit_stereo(vo_ctx *ctx, const uint8_t *left, const uint8_t *right, int row_stride,
+                           size_t frame_stride, const vo_stereo_cfg *stereo);
+/* Stereo matches of one frame of the last completed stereo batch: per left
+ * key point the right index (-1), disparity (-1) and depth (NaN); any pointer
+ * may be NULL. */
+int vo_batch_get_stereo(vo_ctx *ctx, int frame, int32_t *right_idx, float *disparity, float *depth,
+                        int *n_matched);
 /* Wait for the submitted batch; results: batch entries (host memory). */
 int vo_batch_wait(vo_ctx *ctx, vo_frame_result *results);
 /* Per-frame outputs of the last completed batch (host or device pointers;

@@ -99,3 +99,63 @@ def test_pose_from_stereo_depth(ctx, oracle):
         # 33 mm of motion seen through depths that carry the 1-px disparity quantisation (about 3 % at 5 m)
         assert np.linalg.norm(res["tvec"][f] - t_t) < 12.0
         assert np.abs(oracle.rodrigues(res["rvec"][f]) - R_t).max() < 3e-3
+
+
+@pytest.mark.parametrize("detector_levels", [8, 0])
+def test_stereo_batch_pipeline(oracle, detector_levels):
+    """vo_batch_submit_stereo: left and right sequences of two rigs per batch, depth from the on-device stereo
+    matcher; every frame against the oracle run on the oracle's own stereo depth planes, over two batches (so the
+    planes must be back to all-NaN in between)."""
+    from oracle.pipeline import OracleStream
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F, NB, N = 2, 2, 2, 800
+    rigs = []
+    for s in range(S):
+        scene = synth.Scene(6100 + s, relief=2.0)
+        rigs.append((synth.make_sequence(cam, F * NB, 6100 + s, 3, scene=scene),
+                     synth.make_sequence(cam, F * NB, 6200 + s, 3, scene=scene, baseline_mm=BASELINE_MM)))
+    ctx = capi.Context(0, cam.width, cam.height, N + 64, 2 * S * F)
+    try:
+        ctx.batch_configure(cam.width, cam.height, 3, n_streams=S, frames_per_stream=F, max_features=N, camera=K,
+                            orb_levels=detector_levels)
+        refs = [OracleStream(K, N, 20, orb_levels=detector_levels, feature_cap=ctx.max_features) for _ in range(S)]
+        det = (lambda g: oracle.orb_detect(g, N, 1.2, 8, 20)) if detector_levels else (lambda g: oracle.detect(g, N, 20))
+        for nb in range(NB):
+            fr = [nb * F + f for f in range(F)]
+            left = np.stack([rigs[s][0]["frames"][i] for s in range(S) for i in fr])
+            right = np.stack([rigs[s][1]["frames"][i] for s in range(S) for i in fr])
+            ctx.batch_submit_stereo(left, right, BASELINE_MM, band=2.0, min_disp=1.0, max_disp=200.0, ratio=0.8)
+            res = ctx.batch_wait()
+            for s in range(S):
+                for f in range(F):
+                    b = s * F + f
+                    kl, dl = det(oracle.gray(left[b]))
+                    kr, dr = det(oracle.gray(right[b]))
+                    kl, dl, kr, dr = kl[:ctx.max_features], dl[:ctx.max_features], kr[:ctx.max_features], dr[:ctx.max_features]
+                    ridx, disp, depth, plane = oracle.stereo_match(kl, dl, kr, dr, cam.fx, BASELINE_MM, 2.0, 1.0, 200.0,
+                                                                   0.8, size=(cam.width, cam.height))
+                    g_ridx, g_disp, g_depth = ctx.batch_stereo(b)
+                    assert np.array_equal(g_ridx, ridx) and np.array_equal(g_disp, disp) and _nan_equal(g_depth, depth)
+                    r = refs[s].process(left[b], plane)
+                    k, d = ctx.batch_features(b)
+                    assert np.array_equal(k.view(np.uint8), r["kps"].view(np.uint8)) and np.array_equal(d, r["desc"])
+                    m, p3 = ctx.batch_matches(b, 2)
+                    assert np.array_equal(m, r["valid"]) and np.array_equal(p3, r["pts3"])
+                    assert bool(res["pnp_success"][b]) == r["pnp_success"]
+                    if r["pnp_success"]:
+                        assert np.array_equal(ctx.batch_inliers(b), r["inliers"])
+                        assert np.abs(res["rvec"][b] - r["rvec"]).max() < 1e-6                     # rad
+                        assert np.abs(res["tvec"][b] - r["tvec"]).max() < 1e-6 * max(1.0, np.linalg.norm(r["tvec"]))
+            assert res["pnp_success"][1] and res["pnp_success"][F + 1]
+        # too small a context is refused
+        small = capi.Context(0, cam.width, cam.height, N + 64, S * F)
+        try:
+            small.batch_configure(cam.width, cam.height, 3, n_streams=S, frames_per_stream=F, max_features=N, camera=K)
+            with pytest.raises(Exception):
+                small.batch_submit_stereo(left, right, BASELINE_MM)
+        finally:
+            small.close()
+    finally:
+        ctx.close()

@@ -43,6 +43,11 @@ class VoBatchCfg(C.Structure):
                 ("orb_levels", C.c_int), ("orb_scale_factor", C.c_float)]
 
 
+class VoStereoCfg(C.Structure):
+    _fields_ = [("baseline", C.c_double), ("band", C.c_float), ("min_disparity", C.c_float),
+                ("max_disparity", C.c_float), ("ratio", C.c_float)]
+
+
 RESULT_DTYPE = np.dtype([("n_keypoints", "<i4"), ("n_ratio", "<i4"), ("f_found", "<i4"),
                          ("f_iters", "<i4"), ("f_inliers", "<i4"), ("n_matches", "<i4"),
                          ("n_tracked", "<i4"), ("n_3d", "<i4"), ("pnp_success", "<i4"),
@@ -94,6 +99,8 @@ EXPORTS = {
     "vo_batch_set_camera": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double]),
     "vo_batch_set_previous": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "vo_batch_submit": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _P, C.c_int, C.c_size_t]),
+    "vo_batch_submit_stereo": (C.c_int, [_P, _P, _P, C.c_int, C.c_size_t, C.POINTER(VoStereoCfg)]),
+    "vo_batch_get_stereo": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "vo_batch_wait": (C.c_int, [_P, _P]),
     "vo_batch_get_features": (C.c_int, [_P, C.c_int, _P, _P, _P]),
     "vo_batch_get_matches": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
@@ -379,6 +386,34 @@ class Context:
             self._keep.append(depth)
             dptr, drow, dfr = _ptr(depth), cfg.width, cfg.width * cfg.height
         self._check(self._lib.vo_batch_submit(self._h, _ptr(frames), row, row * cfg.height, dptr, drow, dfr))
+
+    def batch_submit_stereo(self, left, right, baseline, band=2.0, min_disp=1.0, max_disp=256.0, ratio=0.8):
+        """left / right: (batch, H, W[, C]) uint8 host arrays, or (pointer, row_stride, frame_stride) tuples of
+        device memory sharing one layout."""
+        st = VoStereoCfg(baseline, band, min_disp, max_disp, ratio)
+        cfg = self._bcfg
+        if isinstance(left, tuple):
+            (lp, row, fr), rp = left, right[0]
+            self._check(self._lib.vo_batch_submit_stereo(self._h, lp, rp, row, fr, C.byref(st)))
+            return
+        left, right = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        assert left.shape == right.shape and left.shape[0] == self._batch
+        row = cfg.width * cfg.channels
+        self._keep = [left, right]
+        self._check(self._lib.vo_batch_submit_stereo(self._h, _ptr(left), _ptr(right), row, row * cfg.height,
+                                                     C.byref(st)))
+
+    def batch_stereo(self, frame: int):
+        """(right_idx, disparity, depth) per left key point of a frame of the last stereo batch."""
+        n = len(self.batch_features(frame)[0])
+        ridx = np.zeros(max(n, 1), np.int32)
+        disp = np.zeros(max(n, 1), np.float32)
+        depth = np.zeros(max(n, 1), np.float32)
+        nm = C.c_int(0)
+        self._check(self._lib.vo_batch_get_stereo(self._h, frame, _ptr(ridx), _ptr(disp), _ptr(depth),
+                                                  C.addressof(nm)))
+        assert nm.value == int((ridx[:n] >= 0).sum())
+        return ridx[:n].copy(), disp[:n].copy(), depth[:n].copy()
 
     def batch_wait(self) -> np.ndarray:
         res = np.zeros(self._batch, RESULT_DTYPE)

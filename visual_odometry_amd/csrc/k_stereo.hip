@@ -22,16 +22,23 @@ constexpr int ST_TILE = 128;    // train key points staged per step
 constexpr uint32_t ST_NONE = 0xffffffffu;
 
 // Two smallest keys (distance << 16 | train index) of every query over the
-// train slice of this block.  sign = +1: queries are left key points
-// (disparity = xq - xt); -1: queries are right ones.  partial: nq x splits.
-__global__ __launch_bounds__(ST_THREADS) void k_band_knn2(const vo_kp *__restrict__ qk, const uint8_t *__restrict__ qd,
-                                                         int nq, const vo_kp *__restrict__ tk,
-                                                         const uint8_t *__restrict__ td, int nt, float band,
-                                                         float min_disp, float max_disp, int sign, int splits,
-                                                         uint2 *__restrict__ partial)
+// train slice of this block, for frame blockIdx.z of a batch: queries are the
+// key points of feature slot q_slot0 + z, trains those of t_slot0 + z.
+// sign = +1: queries are left key points (disparity = xq - xt); -1: queries are
+// right ones.  partial: frames x kp_stride x splits.
+__global__ __launch_bounds__(ST_THREADS) void k_band_knn2(const vo_kp *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                                         const int *__restrict__ nkp, int kp_stride, int q_slot0,
+                                                         int t_slot0, float band, float min_disp, float max_disp,
+                                                         int sign, int splits, uint2 *__restrict__ partial)
 {
     __shared__ uint4 s_desc[ST_TILE][2];
     __shared__ float2 s_xy[ST_TILE];
+    const int z = blockIdx.z;
+    const int nq = min(nkp[q_slot0 + z], kp_stride), nt = min(nkp[t_slot0 + z], kp_stride);
+    if ((int)(blockIdx.x * ST_THREADS) >= nq) return;  // block-uniform
+    const vo_kp *qk = kps + (size_t)(q_slot0 + z) * kp_stride, *tk = kps + (size_t)(t_slot0 + z) * kp_stride;
+    const uint8_t *qd = desc + (size_t)(q_slot0 + z) * kp_stride * 32, *td = desc + (size_t)(t_slot0 + z) * kp_stride * 32;
+    partial += (size_t)z * kp_stride * splits;
     const int tid = threadIdx.x, q = blockIdx.x * ST_THREADS + tid, split = blockIdx.y;
     const int per = (nt + splits - 1) / splits;
     const int t_lo = split * per, t_hi = min(nt, t_lo + per);
@@ -79,25 +86,32 @@ __device__ __forceinline__ void merge_top2(const uint2 *__restrict__ p, int spli
     }
 }
 
-// One thread per left key point: ratio test, cross-check, disparity, depth, and
-// the sparse depth plane (bits of a positive float order like the value, so an
-// unsigned atomic minimum keeps the nearest depth where key points share a pixel;
-// the plane is pre-filled with 0xffffffff, a NaN).
-__global__ __launch_bounds__(ST_THREADS) void k_stereo_finalize(const vo_kp *__restrict__ lk, const vo_kp *__restrict__ rk,
-                                                               int nl, const uint2 *__restrict__ fwd,
+// One thread per left key point of frame blockIdx.y: ratio test, cross-check,
+// disparity, depth, and the sparse depth plane (bits of a positive float order
+// like the value, so an unsigned atomic minimum keeps the nearest depth where
+// key points share a pixel; the plane holds 0xffffffff, a NaN, elsewhere).
+// Per-key-point outputs may be null.
+__global__ __launch_bounds__(ST_THREADS) void k_stereo_finalize(const vo_kp *__restrict__ kps, const int *__restrict__ nkp,
+                                                               int kp_stride, int l_slot0, int r_slot0,
+                                                               const uint2 *__restrict__ fwd,
                                                                const uint2 *__restrict__ bwd, int splits, float ratio,
                                                                double fx, double baseline, int32_t *__restrict__ right_idx,
                                                                float *__restrict__ disparity, float *__restrict__ depth,
                                                                uint32_t *__restrict__ plane, int w, int h,
                                                                int *__restrict__ n_matched)
 {
+    const int z = blockIdx.y;
+    const int nl = min(nkp[l_slot0 + z], kp_stride);
+    const vo_kp *lk = kps + (size_t)(l_slot0 + z) * kp_stride, *rk = kps + (size_t)(r_slot0 + z) * kp_stride;
+    fwd += (size_t)z * kp_stride * splits;
+    bwd += (size_t)z * kp_stride * splits;
     const int i = blockIdx.x * ST_THREADS + threadIdx.x;
     bool ok = false;
     if (i < nl) {
         uint32_t k0, k1;
         merge_top2(fwd + (size_t)i * splits, splits, k0, k1);
         int j = -1;
-        float d = -1.f, z = __uint_as_float(0x7fc00000u);
+        float d = -1.f, zz = __uint_as_float(0x7fc00000u);
         if (k0 != ST_NONE) {
             j = (int)(k0 & 0xffffu);
             ok = k1 == ST_NONE || (float)(k0 >> 16) < ratio * (float)(k1 >> 16);
@@ -109,33 +123,57 @@ __global__ __launch_bounds__(ST_THREADS) void k_stereo_finalize(const vo_kp *__r
         }
         if (ok) {
             d = lk[i].x - rk[j].x;
-            z = (float)(fx * baseline / (double)d);
+            zz = (float)(fx * baseline / (double)d);
             const int u = (int)rintf(lk[i].x), v = (int)rintf(lk[i].y);
-            if (plane && u >= 0 && u < w && v >= 0 && v < h) atomicMin(&plane[(size_t)v * w + u], __float_as_uint(z));
+            if (plane && u >= 0 && u < w && v >= 0 && v < h)
+                atomicMin(&plane[(size_t)z * w * h + (size_t)v * w + u], __float_as_uint(zz));
         } else {
             j = -1;
         }
-        right_idx[i] = j;
-        disparity[i] = d;
-        depth[i] = z;
+        if (right_idx) right_idx[(size_t)z * kp_stride + i] = j;
+        if (disparity) disparity[(size_t)z * kp_stride + i] = d;
+        if (depth) depth[(size_t)z * kp_stride + i] = zz;
     }
     const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_matched, __popcll(m));
+    if ((threadIdx.x & 63) == 0 && m && n_matched) atomicAdd(&n_matched[z], __popcll(m));
+}
+
+// Restore the all-NaN state of the depth planes: every pixel a left key point of the batch rounds to.
+__global__ __launch_bounds__(ST_THREADS) void k_stereo_clear(const vo_kp *__restrict__ kps, const int *__restrict__ nkp,
+                                                            int kp_stride, int l_slot0, uint32_t *__restrict__ plane,
+                                                            int w, int h)
+{
+    const int z = blockIdx.y;
+    const int nl = min(nkp[l_slot0 + z], kp_stride);
+    const int i = blockIdx.x * ST_THREADS + threadIdx.x;
+    if (i >= nl) return;
+    const vo_kp kp = kps[(size_t)(l_slot0 + z) * kp_stride + i];
+    const int u = (int)rintf(kp.x), v = (int)rintf(kp.y);
+    if (u >= 0 && u < w && v >= 0 && v < h) plane[(size_t)z * w * h + (size_t)v * w + u] = 0xffffffffu;
 }
 
 }  // namespace
 
-void launch_stereo_match(const vo_kp *lk, const uint8_t *ld, int nl, const vo_kp *rk, const uint8_t *rd, int nr,
-                         float band, float min_disp, float max_disp, float ratio, double fx, double baseline,
-                         int splits, uint2 *fwd, uint2 *bwd, int32_t *right_idx, float *disparity, float *depth,
-                         uint32_t *plane, int w, int h, int *n_matched, hipStream_t s)
+void launch_stereo_match(const vo_kp *kps, const uint8_t *desc, const int *nkp, int kp_stride, int l_slot0,
+                         int r_slot0, int frames, float band, float min_disp, float max_disp, float ratio, double fx,
+                         double baseline, int splits, uint2 *fwd, uint2 *bwd, int32_t *right_idx, float *disparity,
+                         float *depth, uint32_t *plane, int w, int h, int *n_matched, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_band_knn2, dim3((nl + ST_THREADS - 1) / ST_THREADS, splits), dim3(ST_THREADS), 0, s, lk, ld, nl,
-                       rk, rd, nr, band, min_disp, max_disp, +1, splits, fwd);
-    hipLaunchKernelGGL(k_band_knn2, dim3((nr + ST_THREADS - 1) / ST_THREADS, splits), dim3(ST_THREADS), 0, s, rk, rd, nr,
-                       lk, ld, nl, band, min_disp, max_disp, -1, splits, bwd);
-    hipLaunchKernelGGL(k_stereo_finalize, dim3((nl + ST_THREADS - 1) / ST_THREADS), dim3(ST_THREADS), 0, s, lk, rk, nl,
-                       fwd, bwd, splits, ratio, fx, baseline, right_idx, disparity, depth, plane, w, h, n_matched);
+    const int qb = (kp_stride + ST_THREADS - 1) / ST_THREADS;
+    hipLaunchKernelGGL(k_band_knn2, dim3(qb, splits, frames), dim3(ST_THREADS), 0, s, kps, desc, nkp, kp_stride,
+                       l_slot0, r_slot0, band, min_disp, max_disp, +1, splits, fwd);
+    hipLaunchKernelGGL(k_band_knn2, dim3(qb, splits, frames), dim3(ST_THREADS), 0, s, kps, desc, nkp, kp_stride,
+                       r_slot0, l_slot0, band, min_disp, max_disp, -1, splits, bwd);
+    hipLaunchKernelGGL(k_stereo_finalize, dim3(qb, frames), dim3(ST_THREADS), 0, s, kps, nkp, kp_stride, l_slot0,
+                       r_slot0, fwd, bwd, splits, ratio, fx, baseline, right_idx, disparity, depth, plane, w, h,
+                       n_matched);
+}
+
+void launch_stereo_clear(const vo_kp *kps, const int *nkp, int kp_stride, int l_slot0, int frames, uint32_t *plane,
+                         int w, int h, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stereo_clear, dim3((kp_stride + ST_THREADS - 1) / ST_THREADS, frames), dim3(ST_THREADS), 0, s,
+                       kps, nkp, kp_stride, l_slot0, plane, w, h);
 }
 
 }  // namespace vo

@@ -262,8 +262,11 @@ int vo_batch_reset(vo_ctx *c)
     return VO_OK;
 }
 
-int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride, const float *depth,
-                    int depth_row_stride, size_t depth_frame_stride)
+// vo_batch_submit and vo_batch_submit_stereo: with `right` (and `st`) the depth planes come from the stereo
+// matcher instead of the caller
+static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride, const float *depth,
+                        int depth_row_stride, size_t depth_frame_stride, const uint8_t *right,
+                        const vo_stereo_cfg *st)
 {
     if (!c) return VO_ERR_ARG;
     if (!c->configured) return bfail(c, VO_ERR_STATE, "vo_batch_submit: configure first");
@@ -275,6 +278,15 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         return bfail(c, VO_ERR_ARG, "vo_batch_submit: bad frame strides");
     if (depth && (depth_row_stride < b.width || depth_frame_stride < (size_t)depth_row_stride * b.height))
         return bfail(c, VO_ERR_ARG, "vo_batch_submit: bad depth strides");
+    if (right) {
+        if (!st || !(st->baseline > 0) || !(st->min_disparity > 0) || !(st->max_disparity >= st->min_disparity) ||
+            !(st->band >= 0) || !(st->ratio > 0))
+            return bfail(c, VO_ERR_ARG, "vo_batch_submit_stereo: bad stereo parameters");
+        if (2 * B > c->cfg.max_batch)
+            return bfail(c, VO_ERR_ARG, "vo_batch_submit_stereo: the context needs max_batch >= %d (has %d)", 2 * B,
+                         c->cfg.max_batch);
+        if (!b.enable_pose) return bfail(c, VO_ERR_ARG, "vo_batch_submit_stereo: the pose stage is not configured");
+    }
     HIP_TRY(c, hipSetDevice(c->device));
 
     if (c->streams_started && !c->first_pairs_linked) {
@@ -288,6 +300,9 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         c->first_pairs_linked = true;
     }
 
+    const int row_stride_in = row_stride;
+    const size_t frame_stride_in = frame_stride;
+    const bool right_on_host = right && !is_device_ptr(right);
     const uint8_t *src = frames;
     if (!is_device_ptr(frames)) {
         for (int i = 0; i < B; i++)
@@ -298,8 +313,18 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         row_stride = row_bytes;
         frame_stride = (size_t)row_bytes * b.height;
     }
+    const uint8_t *rsrc = right;
+    if (right_on_host) {
+        uint8_t *stage = c->d_in + (size_t)B * row_bytes * b.height;  // second half of the staging area
+        for (int i = 0; i < B; i++)
+            HIP_TRY(c, hipMemcpy2DAsync(stage + (size_t)i * row_bytes * b.height, row_bytes,
+                                        right + i * frame_stride_in, row_stride_in, row_bytes,
+                                        b.height, hipMemcpyHostToDevice, c->stream));
+        rsrc = stage;
+    }
     const float *dsrc = depth;
     if (depth && b.enable_pose && !is_device_ptr(depth)) {
+        c->depth_planes_nan = false;
         for (int i = 0; i < B; i++)
             HIP_TRY(c, hipMemcpy2DAsync(c->d_depth + (size_t)i * b.width * b.height, sizeof(float) * b.width,
                                         depth + i * depth_frame_stride, sizeof(float) * depth_row_stride,
@@ -309,17 +334,50 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
         depth_frame_stride = (size_t)b.width * b.height;
     }
     if (!b.enable_pose) dsrc = nullptr;
+    const int r_slot0 = S + B;  // feature slots of the right images
+    int rc;
+    if (right) {
+        if ((rc = c->ensure_stereo())) return rc;
+        if (!c->depth_planes_nan) {
+            HIP_TRY(c, hipMemsetAsync(c->d_depth, 0xff, sizeof(float) * (size_t)b.width * b.height * B, c->stream));
+            c->depth_planes_nan = true;
+        }
+        // the right images first, without timing marks: the marks of the detector stages are the left images'
+        const int rs = right_on_host ? row_bytes : row_stride_in;
+        const size_t fs = right_on_host ? (size_t)row_bytes * b.height : frame_stride_in;
+        c->marks_on = false;
+        if (b.orb_levels > 0) {
+            if ((rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f, b.orb_levels,
+                                    b.max_features, B)))
+                return rc;
+            c->enqueue_detect_orb(rsrc, b.width, b.height, rs, fs, b.channels, b.fast_threshold, B, r_slot0);
+        } else
+            c->enqueue_detect(rsrc, b.width, b.height, rs, fs, b.channels, b.max_features, b.fast_threshold, B, r_slot0);
+        c->marks_on = true;
+        dsrc = c->d_depth;
+        depth_row_stride = b.width;
+        depth_frame_stride = (size_t)b.width * b.height;
+    }
 
     if (b.orb_levels > 0) {
         // a single-frame ORB operator call may have re-planned the pyramid since configure
-        const int rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f,
-                                     b.orb_levels, b.max_features, B);
+        rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f, b.orb_levels,
+                           b.max_features, B);
         if (rc) return rc;
         c->enqueue_detect_orb(src, b.width, b.height, row_stride, frame_stride, b.channels, b.fast_threshold, B,
                               /*first_slot=*/S);
     } else
         c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
                           b.fast_threshold, B, /*first_slot=*/S);
+    if (right) {
+        // depth planes of the batch from the left / right key points (the kNN partial buffers are free until
+        // the temporal matcher runs)
+        HIP_TRY(c, hipMemsetAsync(c->d_st_n, 0, sizeof(int) * B, c->stream));
+        launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, S, r_slot0, B, st->band, st->min_disparity,
+                            st->max_disparity, st->ratio, b.fx, st->baseline, kKnnSplits, c->d_partial, c->d_partial_rev,
+                            c->d_st_idx, c->d_st_disp, c->d_st_depth, reinterpret_cast<uint32_t *>(c->d_depth), b.width,
+                            b.height, c->d_st_n, c->stream);
+    }
     c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
     c->mark(8);
     launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
@@ -329,6 +387,9 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
                               c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
                               depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
                               c->d_bpinfo, B, c->stream);
+    if (right)  // the planes go back to all-NaN for the next stereo batch
+        launch_stereo_clear(c->d_kps, c->d_nkp, c->kp_stride, S, B, reinterpret_cast<uint32_t *>(c->d_depth), b.width,
+                            b.height, c->stream);
     c->mark(10);
     if (!(b.enable_pose && dsrc)) {
         HIP_TRY(c, hipMemsetAsync(c->d_pose, 0, sizeof(int) * 4 * B, c->stream));
@@ -348,6 +409,41 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));
     c->submitted = true;
     c->streams_started = true;
+    c->last_batch_stereo = right != nullptr;
+    return VO_OK;
+}
+
+int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride, const float *depth,
+                    int depth_row_stride, size_t depth_frame_stride)
+{
+    return batch_submit(c, frames, row_stride, frame_stride, depth, depth_row_stride, depth_frame_stride, nullptr,
+                        nullptr);
+}
+
+int vo_batch_submit_stereo(vo_ctx *c, const uint8_t *left, const uint8_t *right, int row_stride, size_t frame_stride,
+                           const vo_stereo_cfg *stereo)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!right || !stereo) return bfail(c, VO_ERR_ARG, "vo_batch_submit_stereo: null pointer");
+    return batch_submit(c, left, row_stride, frame_stride, nullptr, 0, 0, right, stereo);
+}
+
+int vo_batch_get_stereo(vo_ctx *c, int frame, int32_t *right_idx, float *disparity, float *depth, int *n_matched)
+{
+    if (!c) return VO_ERR_ARG;
+    if (!c->configured || c->submitted || !c->last_batch_stereo)
+        return bfail(c, VO_ERR_STATE, "vo_batch_get_stereo: no completed stereo batch");
+    const int B = c->bcfg.n_streams * c->bcfg.frames_per_stream;
+    if (frame < 0 || frame >= B) return bfail(c, VO_ERR_ARG, "vo_batch_get_stereo: frame %d of %d", frame, B);
+    HIP_TRY(c, hipSetDevice(c->device));
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->d_nkp + c->bcfg.n_streams + frame, sizeof(int), hipMemcpyDeviceToHost));
+    n = n < c->kp_stride ? n : c->kp_stride;
+    const size_t o = (size_t)frame * c->kp_stride;
+    if (right_idx && n) HIP_TRY(c, hipMemcpy(right_idx, c->d_st_idx + o, sizeof(int32_t) * n, hipMemcpyDefault));
+    if (disparity && n) HIP_TRY(c, hipMemcpy(disparity, c->d_st_disp + o, sizeof(float) * n, hipMemcpyDefault));
+    if (depth && n) HIP_TRY(c, hipMemcpy(depth, c->d_st_depth + o, sizeof(float) * n, hipMemcpyDefault));
+    if (n_matched) HIP_TRY(c, hipMemcpy(n_matched, c->d_st_n + frame, sizeof(int), hipMemcpyDeviceToHost));
     return VO_OK;
 }
 

@@ -541,6 +541,18 @@ int vo_match_features_ex(vo_ctx *c, const vo_kp *prev_kps, const uint8_t *prev_d
     return VO_OK;
 }
 
+int vo_ctx::ensure_stereo()
+{
+    vo_ctx *ctx = this;
+    if (d_st_idx) return VO_OK;
+    const size_t n = (size_t)kp_stride * cfg.max_batch;
+    HIP_TRY(ctx, hipMalloc(&d_st_idx, sizeof(int32_t) * n));
+    HIP_TRY(ctx, hipMalloc(&d_st_disp, sizeof(float) * n));
+    HIP_TRY(ctx, hipMalloc(&d_st_depth, sizeof(float) * n));
+    HIP_TRY(ctx, hipMalloc(&d_st_n, sizeof(int) * cfg.max_batch));
+    return VO_OK;
+}
+
 static bool is_device_pointer(const void *p)
 {
     hipPointerAttribute_t a;
@@ -566,13 +578,8 @@ int vo_stereo_depth(vo_ctx *c, const vo_kp *left_kps, const uint8_t *left_desc, 
         (n_right && (!right_kps || !right_desc)))
         return fail(c, VO_ERR_ARG, "vo_stereo_depth: null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->d_st_idx) {
-        const size_t n = (size_t)c->cfg.max_features;
-        HIP_TRY(c, hipMalloc(&c->d_st_idx, sizeof(int32_t) * n));
-        HIP_TRY(c, hipMalloc(&c->d_st_disp, sizeof(float) * n));
-        HIP_TRY(c, hipMalloc(&c->d_st_depth, sizeof(float) * n));
-        HIP_TRY(c, hipMalloc(&c->d_st_n, sizeof(int)));
-    }
+    int rc;
+    if ((rc = c->ensure_stereo())) return rc;
     uint32_t *d_plane = nullptr;
     const size_t plane_px = plane ? (size_t)w * h : 0;
     if (plane) {
@@ -590,16 +597,13 @@ int vo_stereo_depth(vo_ctx *c, const vo_kp *left_kps, const uint8_t *left_desc, 
         HIP_TRY(c, hipMemsetAsync(d_plane, 0xff, sizeof(float) * plane_px, c->stream));  // all NaN
     }
     if (n_matched) *n_matched = 0;
-    int rc;
     if (n_left > 0 && n_right > 0) {
         if ((rc = upload_features(c, c->op_slot0, left_kps, left_desc, n_left))) return rc;
         if ((rc = upload_features(c, c->op_slot1, right_kps, right_desc, n_right))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_st_n, 0, sizeof(int), c->stream));
-        launch_stereo_match(c->d_kps + (size_t)c->op_slot0 * c->kp_stride, c->d_desc + (size_t)c->op_slot0 * c->kp_stride * 32,
-                            n_left, c->d_kps + (size_t)c->op_slot1 * c->kp_stride,
-                            c->d_desc + (size_t)c->op_slot1 * c->kp_stride * 32, n_right, band, min_disp, max_disp, ratio,
-                            fx, baseline, kKnnSplits, c->d_partial, c->d_partial_rev, c->d_st_idx, c->d_st_disp,
-                            c->d_st_depth, d_plane, w, h, c->d_st_n, c->stream);
+        launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, c->op_slot0, c->op_slot1, 1, band, min_disp,
+                            max_disp, ratio, fx, baseline, kKnnSplits, c->d_partial, c->d_partial_rev, c->d_st_idx,
+                            c->d_st_disp, c->d_st_depth, d_plane, w, h, c->d_st_n, c->stream);
         if ((rc = finish(c, "vo_stereo_depth"))) return rc;
         HIP_TRY(c, hipMemcpy(right_idx, c->d_st_idx, sizeof(int32_t) * n_left, hipMemcpyDefault));
         HIP_TRY(c, hipMemcpy(disparity, c->d_st_disp, sizeof(float) * n_left, hipMemcpyDefault));

@@ -67,6 +67,11 @@ struct vo_ctx {
     float *d_st_disp = nullptr, *d_st_depth = nullptr, *d_st_plane = nullptr;
     int *d_st_n = nullptr;
     size_t st_plane_cap = 0;
+    int ensure_stereo();
+    bool depth_planes_nan = false;  // d_depth holds nothing but NaN (stereo batches keep it that way)
+    bool marks_on = true;           // timing events are recorded by mark()
+    vo_stereo_cfg stereo_cfg{};
+    bool last_batch_stereo = false;
 
     // pose stage
     float *d_depth = nullptr;  // staging for depth handed over from the host
@@ -92,7 +97,7 @@ struct vo_ctx {
     hipEvent_t ev[kStages + 1] = {};
     void mark(int i)
     {
-        if (timing) (void)hipEventRecord(ev[i], stream);
+        if (timing && marks_on) (void)hipEventRecord(ev[i], stream);
     }
 
     static constexpr size_t kPinnedBytes = 1 << 20;

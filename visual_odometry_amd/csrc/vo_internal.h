@@ -126,15 +126,21 @@ void launch_equalize_lut(const uint32_t *hist, int total, uint8_t *lut, hipStrea
 void launch_enhance_blur_mask(const uint8_t *src, int w, int h, int pitch, const uint8_t *lut, int n_taps,
                               const uint16_t *taps, uint8_t *enh, uint8_t *den, uint8_t *msk, hipStream_t s);
 
-// Stereo front end: band-limited Hamming matching left->right and right->left
-// (two smallest keys per query and train split in fwd / bwd, n x splits),
-// then ratio test, cross-check, disparity, depth = fx * baseline / disparity and
-// an atomic-minimum scatter into the w x h depth plane (pre-filled with 0xff
-// bytes; may be null).  *n_matched must be zero on entry.
-void launch_stereo_match(const vo_kp *lk, const uint8_t *ld, int nl, const vo_kp *rk, const uint8_t *rd, int nr,
-                         float band, float min_disp, float max_disp, float ratio, double fx, double baseline,
-                         int splits, uint2 *fwd, uint2 *bwd, int32_t *right_idx, float *disparity, float *depth,
-                         uint32_t *plane, int w, int h, int *n_matched, hipStream_t s);
+// Stereo front end, batched over `frames` pairs: left key points in feature slots
+// l_slot0 + f, right ones in r_slot0 + f.  Band-limited Hamming matching
+// left->right and right->left (two smallest keys per query and train split in
+// fwd / bwd, frames x kp_stride x splits), then ratio test, cross-check,
+// disparity, depth = fx * baseline / disparity (per-key-point arrays of
+// frames x kp_stride, may be null) and an atomic-minimum scatter into the
+// frames x h x w depth planes (all 0xff bytes = NaN beforehand; may be null).
+// n_matched (frames entries, may be null) must be zero on entry.
+void launch_stereo_match(const vo_kp *kps, const uint8_t *desc, const int *nkp, int kp_stride, int l_slot0,
+                         int r_slot0, int frames, float band, float min_disp, float max_disp, float ratio, double fx,
+                         double baseline, int splits, uint2 *fwd, uint2 *bwd, int32_t *right_idx, float *disparity,
+                         float *depth, uint32_t *plane, int w, int h, int *n_matched, hipStream_t s);
+// Puts NaN back at every pixel a left key point of the batch rounds to.
+void launch_stereo_clear(const vo_kp *kps, const int *nkp, int kp_stride, int l_slot0, int frames, uint32_t *plane,
+                         int w, int h, hipStream_t s);
 
 // cv::undistort of a gray plane (k = k1 k2 p1 p2 k3 k4 k5 k6); dst rows must be
 // padded to a multiple of 128 bytes
