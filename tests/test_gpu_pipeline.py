@@ -7,7 +7,7 @@ from visual_odometry_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-R_TOL = 1e-6  # rad, north-star tolerance for the recovered rotation
+R_TOL = 1e-6  # rad: tolerance asked of the recovered rotation
 T_TOL = 1e-6  # relative to |t|
 
 
