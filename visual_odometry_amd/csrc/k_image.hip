@@ -76,7 +76,7 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride, size
 // ----------------------- fused gray + FAST + NMS + emit + blur (one tile)
 
 constexpr int FE_TW = 128;             // interior tile width
-constexpr int FE_TH = 16;              // interior tile height
+constexpr int FE_TH = 32;              // interior tile height
 constexpr int FE_PITCH = FE_TW + 16;   // LDS row: image x0-4 .. x0+TW+11, 16-B aligned
 constexpr int FE_GROWS = FE_TH + 8;    // gray rows: image y0-4 .. y0+TH+3
 constexpr int FE_SROWS = FE_TH + 2;    // score rows: image y0-1 .. y0+TH
@@ -86,7 +86,8 @@ constexpr int FE_WAVES = FE_THREADS / 64;
 constexpr int FE_HALO_PIX = 2 * (FE_TW + 2) + 2 * FE_TH;             // 1-px rim around the tile
 constexpr int FE_QCAP = FE_TW * FE_TH + FE_HALO_PIX;                  // queue entries a tile can produce
 static_assert(FE_TW == kTileW && FE_TH == kTileH, "candidate lists are indexed by this tile grid");
-static_assert(FE_THREADS == FE_TW / 4 * FE_TH && FE_HALO_PIX <= FE_THREADS, "one quad and one rim pixel per thread");
+constexpr int FE_QPT = FE_TW / 4 * FE_TH / FE_THREADS;  // quads (four pixels of a row) per thread: rows gy + 16 k
+static_assert(FE_THREADS * FE_QPT == FE_TW / 4 * FE_TH && FE_HALO_PIX <= FE_THREADS, "whole quads and one rim pixel per thread");
 
 // FAST-9/16 score of one pixel from its 16 ring values p[] and centre v:
 //   A = max over the 16 arcs of 9 of min(v - p) = v - min_arcs(max_arc p)
@@ -370,7 +371,7 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
             *reinterpret_cast<uint32_t *>(&s_gray[at[u]]) = fe_gray4<CN>(pre[u], packed[u], gd);
 }
 
-// One block = one 128x16 tile of one frame:
+// One block = one 128x32 tile of one frame:
 //   0. the tile plus a 4-px apron is staged in LDS as 8-bit gray (BGR/BGRA are
 //      converted on the way in; 16-B vector loads, all issued before first use);
 //   1. cheap FAST pre-test on the tile and its 1-px rim in packed 16-bit
@@ -446,35 +447,38 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(3);
     FE_CUT(1);
 
-    const int gx = tid & 31, gy = tid >> 5;  // 32 groups x 16 rows: this thread's four interior pixels
-    const int x = x0 + gx * 4, y = y0 + gy;  // image position of the first of them
+    const int gx = tid & 31, gy = tid >> 5;  // 32 quad columns x 16 rows: this thread's quads are at rows gy + 16 k
+    const int x = x0 + gx * 4;               // image column of the first pixel of its quads
     const bool want_fast = score.base != nullptr || cand != nullptr;
     int qn = 0;  // entries in the tile queue
 
     if (want_fast) {
-        // ---- 1. pre-test: interior (four pixels per thread) ...
-        // bit i of vm: pixel x+i lies where cv::FAST evaluates (3 px inside the image)
-        uint32_t r01, r23;
-        {
-            const uint32_t up1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 1) * FE_PITCH + gx * 4 + 4]);
-            const uint32_t dn1 = *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 7) * FE_PITCH + gx * 4 + 4]);
-            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4]);
+        // ---- 1. pre-test: interior (FE_QPT quads of four pixels per thread) ...
+        bool pass[4 * FE_QPT];
+        const us2 tt = as_us2((uint32_t)thr * 0x00010001u);
+#pragma unroll
+        for (int k = 0; k < FE_QPT; k++) {
+            const int ry = gy + 16 * k;  // interior row of this quad
+            const uint32_t up1 = *reinterpret_cast<const uint32_t *>(&s_gray[(ry + 1) * FE_PITCH + gx * 4 + 4]);
+            const uint32_t dn1 = *reinterpret_cast<const uint32_t *>(&s_gray[(ry + 7) * FE_PITCH + gx * 4 + 4]);
+            const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(ry + 4) * FE_PITCH + gx * 4]);
             const uint32_t d0 = rm[0], d1 = rm[1], d2 = rm[2];
-            const us2 tt = as_us2((uint32_t)thr * 0x00010001u);
-            r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
-            r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
-        }
-        if (!tile.inside) {  // block-uniform: border tiles mask the pixels cv::FAST does not evaluate
-            uint32_t vm = 0;
-            if (y >= 3 && y < height - 3) {
-                const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
-                if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            uint32_t r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
+            uint32_t r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
+            if (!tile.inside) {  // block-uniform: border tiles mask the pixels cv::FAST does not evaluate
+                // bit i of vm: pixel x+i lies where cv::FAST evaluates (3 px inside the image)
+                const int y = y0 + ry;
+                uint32_t vm = 0;
+                if (y >= 3 && y < height - 3) {
+                    const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
+                    if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                }
+                r01 &= ((vm & 1u) ? 0xffffu : 0u) | ((vm & 2u) ? 0xffff0000u : 0u);
+                r23 &= ((vm & 4u) ? 0xffffu : 0u) | ((vm & 8u) ? 0xffff0000u : 0u);
             }
-            r01 &= ((vm & 1u) ? 0xffffu : 0u) | ((vm & 2u) ? 0xffff0000u : 0u);
-            r23 &= ((vm & 4u) ? 0xffffu : 0u) | ((vm & 8u) ? 0xffff0000u : 0u);
+            pass[4 * k + 0] = (r01 & 0xffffu) != 0; pass[4 * k + 1] = r01 > 0xffffu;
+            pass[4 * k + 2] = (r23 & 0xffffu) != 0; pass[4 * k + 3] = r23 > 0xffffu;
         }
-        const bool pass0 = (r01 & 0xffffu) != 0, pass1 = r01 > 0xffffu;
-        const bool pass2 = (r23 & 0xffffu) != 0, pass3 = r23 > 0xffffu;
         // ... and the 1-px rim around the tile (one pixel per thread of the first waves)
         int hr = -1, hc = 0;
         if (tid < FE_HALO_PIX) {
@@ -493,29 +497,29 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         }
         // queue the survivors: one LDS atomic per wave
         {
-            uint64_t m[5];
-            m[0] = __ballot(pass0); m[1] = __ballot(pass1); m[2] = __ballot(pass2); m[3] = __ballot(pass3);
-            m[4] = __ballot(hr >= 0);
+            uint64_t m[4 * FE_QPT + 1];
+#pragma unroll
+            for (int i = 0; i < 4 * FE_QPT; i++) m[i] = __ballot(pass[i]);
+            m[4 * FE_QPT] = __ballot(hr >= 0);
             uint32_t total = 0;
 #pragma unroll
-            for (int i = 0; i < 5; i++) total += (uint32_t)__popcll(m[i]);
+            for (int i = 0; i <= 4 * FE_QPT; i++) total += (uint32_t)__popcll(m[i]);
             if (total) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&s_qcount, total);
                 base = __builtin_amdgcn_readfirstlane(base);
-                const bool pass[4] = {pass0, pass1, pass2, pass3};
-                const uint32_t q0 = (uint32_t)(((gy + 4) << 8) | (4 + 4 * gx));
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < 4 * FE_QPT; i++) {
                     // base + number of passing lanes below this one
                     const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
                         (uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], base));
+                    const uint32_t q = (uint32_t)(((gy + 16 * (i >> 2) + 4) << 8) | (4 + 4 * gx + (i & 3)));
                     // unconditional store: lanes that did not pass write their own spare slot past the queue
-                    s_queue[pass[i] ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)(q0 + i);
+                    s_queue[pass[i] ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)q;
                     base += (uint32_t)__popcll(m[i]);
                 }
-                const uint32_t pos =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(m[4] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[4], base));
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
+                    (uint32_t)(m[4 * FE_QPT] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[4 * FE_QPT], base));
                 s_queue[hr >= 0 ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)((hr << 8) | hc);
             }
         }
@@ -541,22 +545,24 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         }
     }
 
-    // ---- Gaussian, row pass: row sums of tile rows 1 .. 22, two rows per task, taken by the last
-    // threads of the block so that the waves without queue entries do it
+    // ---- Gaussian, row pass: row sums of tile rows 1 .. FE_HROWS, two rows per task, the last threads of
+    // the block first so that the waves with fewer queue entries take the second round
     if (blur.base) {
-        static_assert(FE_HPAIRS * 32 <= FE_THREADS, "one row-pair task per thread at most");
-        const int t = FE_THREADS - 1 - tid;
-        if (t < FE_HPAIRS * 32) {
-            const int hp = t >> 5, tg = t & 31;
-            const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 1) * FE_PITCH + tg * 4]);
-            const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 2) * FE_PITCH + tg * 4]);
-            uint32_t ha[4], hb[4];
-            hsum7_quad(ra[0], ra[1], ra[2], ha);
-            hsum7_quad(rb[0], rb[1], rb[2], hb);
-            uint4 o;
-            o.x = ha[0] | (hb[0] << 16); o.y = ha[1] | (hb[1] << 16);
-            o.z = ha[2] | (hb[2] << 16); o.w = ha[3] | (hb[3] << 16);
-            *reinterpret_cast<uint4 *>(&s_hpair[hp * FE_TW + tg * 4]) = o;
+#pragma unroll
+        for (int it = 0; it < (FE_HPAIRS * 32 + FE_THREADS - 1) / FE_THREADS; it++) {
+            const int t = FE_THREADS - 1 - tid + it * FE_THREADS;
+            if (t < FE_HPAIRS * 32) {
+                const int hp = t >> 5, tg = t & 31;
+                const uint32_t *ra = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 1) * FE_PITCH + tg * 4]);
+                const uint32_t *rb = reinterpret_cast<const uint32_t *>(&s_gray[(2 * hp + 2) * FE_PITCH + tg * 4]);
+                uint32_t ha[4], hb[4];
+                hsum7_quad(ra[0], ra[1], ra[2], ha);
+                hsum7_quad(rb[0], rb[1], rb[2], hb);
+                uint4 o;
+                o.x = ha[0] | (hb[0] << 16); o.y = ha[1] | (hb[1] << 16);
+                o.z = ha[2] | (hb[2] << 16); o.w = ha[3] | (hb[3] << 16);
+                *reinterpret_cast<uint4 *>(&s_hpair[hp * FE_TW + tg * 4]) = o;
+            }
         }
     }
     FE_STAMP(6);
@@ -606,7 +612,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(8);
 
     // ---- Gaussian, column pass: output rows (2m, 2m+1) from the row pairs m .. m+3
-    if (blur.base && tid >= FE_THREADS - (FE_TH / 2) * 32) {  // the waves that had no corners to suppress
+    static_assert((FE_TH / 2) * 32 == FE_THREADS, "one pair of output rows per thread");
+    if (blur.base) {
         const int ct = FE_THREADS - 1 - tid;
         const int m = ct >> 5, tg = ct & 31;
         uint4 P[4];
@@ -638,13 +645,16 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         if (yy + 1 < height) *reinterpret_cast<uint32_t *>(bp + blur.pitch) = oo;
     }
 
-    if (gray_out.base && y < height)
-        *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
-            *reinterpret_cast<const uint32_t *>(&s_gray[(gy + 4) * FE_PITCH + gx * 4 + 4]);
-
-    if (score.base)  // diagnostic score map; planes are padded to whole tiles: always in bounds
-        *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) =
-            *reinterpret_cast<const uint32_t *>(&s_score[(gy + 1) * FE_PITCH + gx * 4 + 4]);
+#pragma unroll
+    for (int k = 0; k < FE_QPT; k++) {
+        const int ry = gy + 16 * k, y = y0 + ry;
+        if (gray_out.base && y < height)
+            *reinterpret_cast<uint32_t *>(gray_out.base + f * gray_out.plane_stride + (size_t)y * gray_out.pitch + x) =
+                *reinterpret_cast<const uint32_t *>(&s_gray[(ry + 4) * FE_PITCH + gx * 4 + 4]);
+        if (score.base && y < height)  // diagnostic score map
+            *reinterpret_cast<uint32_t *>(score.base + f * score.plane_stride + (size_t)y * score.pitch + x) =
+                *reinterpret_cast<const uint32_t *>(&s_score[(ry + 1) * FE_PITCH + gx * 4 + 4]);
+    }
     FE_STAMP(9);
 }
 
