@@ -173,6 +173,18 @@ __device__ __forceinline__ float key_to_float(uint32_t k)
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
+#ifdef VO_FE_STAMPS
+// Diagnostic build only: cycle stamps of thread 0 of the first 32 frames' blocks, per level.
+__device__ unsigned long long g_os_stamps[8 * 32 * 16];
+#define OS_STAMP(i)                                                                                  \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 32)                                                     \
+            g_os_stamps[(blockIdx.y * 32 + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime();    \
+    } while (0)
+#else
+#define OS_STAMP(i) do { } while (0)
+#endif
+
 // One block per (level, frame): what computeKeyPoints() does to the FAST
 // corners of one pyramid level --
 //   runByImageBorder(31) -> retainBest(2*quota) by FAST score ->
@@ -201,11 +213,13 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     const int f = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
+    OS_STAMP(0);
     // the level's corners as one list (s_buf is free until the gather below)
     uint32_t *c = flat + L.cand_off + (size_t)f * L.tiles * kTileCap;
     const int M = flatten_tile_lists<OS_THREADS>(cand + L.cand_off + (size_t)f * L.tiles * kTileCap,
                                                  tile_count + L.count_off + (size_t)f * L.tiles, L.tiles, c, s_buf,
                                                  s_scan);
+    OS_STAMP(1);
     const uint8_t *img = pyr + (size_t)f * plan.frame_bytes + L.off;
     const bool size_ok = w > 2 * border && h > 2 * border && quota > 0;
 
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
             if (in_border(k & 0xffffffu)) atomicAdd(&s_hist[k >> 24], 1u);
         }
     __syncthreads();
+    OS_STAMP(2);
     {
         // bins are 255 - score: the first bin at which the running count covers 2*quota corners;
         // every bin <= cut survives (all of them when fewer than 2*quota exist)
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     }
     __syncthreads();
 
+    OS_STAMP(3);
     // 2. gather the survivors
     const int cut = s_cut;
     if (cut >= 0)
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __syncthreads();
     const int K1 = min(s_n1, OS_K1CAP);
 
+    OS_STAMP(4);
     // 3. Harris response of each survivor
     for (int i = tid; i < K1; i += OS_THREADS) {
         const uint32_t ras = s_ras[i];
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     }
     __syncthreads();
 
+    OS_STAMP(5);
     // 4. the quota-th largest key by an MSB-first radix select
     uint32_t threshold = 0;
     if (K1 > quota) {
@@ -288,6 +306,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
         threshold = s_prefix;
     }
 
+    OS_STAMP(6);
     // 5. survivors of the second cut, sorted by raster index
     for (int i = tid; i < K1; i += OS_THREADS) {
         if (s_key[i] >= threshold) {
@@ -297,6 +316,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     }
     __syncthreads();
     const int K2 = min(s_n2, kOrbLevelCap);
+    OS_STAMP(7);
     int n_pow2 = 1;
     while (n_pow2 < K2) n_pow2 <<= 1;
     for (int i = K2 + tid; i < n_pow2; i += OS_THREADS) s_oras[i] = 0xffffffffu;
@@ -315,11 +335,13 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
             }
             __syncthreads();
         }
+    OS_STAMP(8);
     const size_t o = ((size_t)f * plan.nlevels + l) * kOrbLevelCap;
     for (int i = tid; i < K2; i += OS_THREADS) {
         lvl_ras[o + i] = s_oras[i];
         lvl_resp[o + i] = key_to_float(s_okey[i]);
     }
+    OS_STAMP(9);
     if (tid == 0) lvl_n[f * plan.nlevels + l] = K2;
 }
 
@@ -585,6 +607,13 @@ void orb_axis_table(int src_n, int dst_n, int padded, uint32_t *out)
         out[d] = ofs | (w1 << 16);
     }
 }
+
+#ifdef VO_FE_STAMPS
+extern "C" int vo_debug_os_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_stamps), sizeof(unsigned long long) * 8 * 32 * 16);
+}
+#endif
 
 void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, const uint32_t *xtab,
                          const uint32_t *ytab, int batch, hipStream_t s)
