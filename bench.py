@@ -228,6 +228,11 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("frames_per_launch") == Bc:
                 measured = {k: v.get("bytes") for k, v in tj["stages"].items()}
+                busy = {k: v.get("valu_busy") for k, v in tj["stages"].items()}
+                if busy.get(dominant) is not None:
+                    # measured vector-ALU occupancy of the dominant kernel (SQ_ACTIVE_INST_VALU pass kept under
+                    # profiles/): the image kernels are instruction-bound long before they are HBM-bound
+                    roof["valu_busy"] = busy[dominant]
         roof["traffic"] = measured.get(dominant)
         stage_roof = {}
         for k, (bound, amount, peak, unit) in work.items():

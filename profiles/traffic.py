@@ -8,7 +8,7 @@ import json
 import sys
 
 
-def main(path, frames_per_launch, out):
+def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
     kb = {}
     for line in open(path):
         parts = line.split()
@@ -42,9 +42,29 @@ def main(path, frames_per_launch, out):
         stages["frontend_upper_levels"] = {
             "bytes": None, "raw_fetch_bytes": d["FETCH_SIZE"][0] * 1024 * n, "write_bytes": d["WRITE_SIZE"][0] * 1024 * n,
             "note": f"{n} launches; 4-byte loads: FETCH_SIZE is uncalibrated for this width, raw value kept"}
+    # vector-ALU occupancy of the same kernels: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, so
+    # busy = 4 * count / (1024 SIMDs * 2.4 GHz * average kernel duration from the kernel trace)
+    if sq_path and kstats_path:
+        sq = {}
+        for line in open(sq_path):
+            parts = line.split()
+            if len(parts) > 2:
+                sq[parts[0]] = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in parts[2:] if "=" in kv}
+        dur = {}
+        for line in open(kstats_path):
+            if line.startswith('"'):
+                name, rest = line[1:].split('",', 1)
+                dur[name] = float(rest.split(",")[2]) * 1e-6  # avg_us
+        for stage, frag in (("frontend_fast_nms_blur", "k_frontendILi4E"), ("frontend_upper_levels", "k_frontendILi1E"),
+                            ("knn2", "k_knn2"), ("pyramid_resize", "k_resize_exact"), ("brief", "k_brief")):
+            a = next((v for k, v in sq.items() if frag in k), None)
+            d = next((v for k, v in dur.items() if frag in k), None)
+            if a and d:
+                stages.setdefault(stage, {"bytes": None})["valu_busy"] = round(
+                    4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * 2.4e9 * d), 3)
     json.dump({"frames_per_launch": frames_per_launch, "source": path, "stages": stages}, open(out, "w"), indent=1)
     print(json.dumps(stages, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), sys.argv[3])
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3], *(sys.argv[4:6] if len(sys.argv) >= 6 else (None, None)))
