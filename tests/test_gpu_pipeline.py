@@ -155,3 +155,32 @@ def test_batch_pipeline_full_orb(ctx, oracle):
                 assert len(np.unique(ref["kps"]["octave"])) == 8
                 if nb or f:
                     assert ref["pnp_success"] and len(ref["matches"]) > 100
+
+
+@pytest.mark.parametrize("levels", [0, 8])
+def test_batch_is_reproducible_run_to_run(ctx, levels):
+    """The same batch twice (streams reset in between): every output identical bit for bit, poses included --
+    no result depends on the order in which blocks or atomics happen to run."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F = 2, 3  # the shared context holds eight frames per batch
+    seqs = [synth.make_sequence(cam, F, seed=7300 + s, channels=3, scene=synth.Scene(7300 + s, relief=2.0))
+            for s in range(S)]
+    frames = np.stack([seqs[s]["frames"][f] for s in range(S) for f in range(F)])
+    depth = np.stack([seqs[s]["depth"][f] for s in range(S) for f in range(F)])
+    ctx.batch_configure(cam.width, cam.height, 3, n_streams=S, frames_per_stream=F, max_features=1200, camera=K,
+                        orb_levels=levels, cross_check=True)
+    runs = []
+    for _ in range(2):
+        ctx.batch_reset()
+        ctx.batch_submit(frames, depth)
+        res = ctx.batch_wait()
+        per_frame = []
+        for b in range(S * F):
+            k, d = ctx.batch_features(b)
+            m, p3 = ctx.batch_matches(b, 2)
+            per_frame.append((k.tobytes(), d.tobytes(), m.tobytes(), p3.tobytes(), ctx.batch_inliers(b).tobytes()))
+        runs.append((res.tobytes(), per_frame))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][1] == runs[1][1]
+    assert res["pnp_success"].reshape(S, F)[:, 1:].all()
