@@ -229,6 +229,7 @@ struct FePre {
 struct FeTile {
     int frame, x0, y0;
     bool inside;  // the tile and its apron lie inside the image: no reflection
+    bool whole;   // every pixel of the tile lies where corners are looked for: no masking
     bool fast;    // border tile of an aligned image of at least 8 x 8: branch-free reflection, vector loads
 };
 
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
                                                          uint32_t *__restrict__ tile_count, int batch,
-                                                         uint32_t inv_tiles_x)
+                                                         uint32_t inv_tiles_x, int margin)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
@@ -428,6 +429,8 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
                       tile.y0 + FE_GROWS - 4 <= height;
         tile.fast = !tile.inside && aligned && width >= 8 && height >= 8;
+        tile.whole = tile.x0 >= margin && tile.x0 + FE_TW <= width - margin && tile.y0 >= margin &&
+                     tile.y0 + FE_TH <= height - margin;
     }
     const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
 
@@ -456,28 +459,47 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
         // ---- 1. pre-test: interior (FE_QPT quads of four pixels per thread) ...
         bool pass[4 * FE_QPT];
         const us2 tt = as_us2((uint32_t)thr * 0x00010001u);
-#pragma unroll
-        for (int k = 0; k < FE_QPT; k++) {
+        // corners are looked for `margin` pixels inside the image (3: where cv::FAST evaluates; more when the
+        // caller drops a wider border anyway)
+        auto pretest = [&](int k, bool masked, uint32_t &r01, uint32_t &r23) {
             const int ry = gy + 16 * k;  // interior row of this quad
             const uint32_t up1 = *reinterpret_cast<const uint32_t *>(&s_gray[(ry + 1) * FE_PITCH + gx * 4 + 4]);
             const uint32_t dn1 = *reinterpret_cast<const uint32_t *>(&s_gray[(ry + 7) * FE_PITCH + gx * 4 + 4]);
             const uint32_t *rm = reinterpret_cast<const uint32_t *>(&s_gray[(ry + 4) * FE_PITCH + gx * 4]);
             const uint32_t d0 = rm[0], d1 = rm[1], d2 = rm[2];
-            uint32_t r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
-            uint32_t r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
-            if (!tile.inside) {  // block-uniform: border tiles mask the pixels cv::FAST does not evaluate
-                // bit i of vm: pixel x+i lies where cv::FAST evaluates (3 px inside the image)
+            r01 = quick_pair<0>(up1, d0, d1, d2, dn1, tt);
+            r23 = quick_pair<2>(up1, d0, d1, d2, dn1, tt);
+            if (masked) {
+                // bit i of vm: pixel x+i lies inside the margin
                 const int y = y0 + ry;
                 uint32_t vm = 0;
-                if (y >= 3 && y < height - 3) {
-                    const int lo = max(3 - x, 0), hi = min(width - 3 - x, 4);
+                if (y >= margin && y < height - margin) {
+                    const int lo = max(margin - x, 0), hi = min(width - margin - x, 4);
                     if (hi > lo) vm = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
                 }
                 r01 &= ((vm & 1u) ? 0xffffu : 0u) | ((vm & 2u) ? 0xffff0000u : 0u);
                 r23 &= ((vm & 4u) ? 0xffffu : 0u) | ((vm & 8u) ? 0xffff0000u : 0u);
             }
-            pass[4 * k + 0] = (r01 & 0xffffu) != 0; pass[4 * k + 1] = r01 > 0xffffu;
-            pass[4 * k + 2] = (r23 & 0xffffu) != 0; pass[4 * k + 3] = r23 > 0xffffu;
+        };
+        uint32_t r01[FE_QPT], r23[FE_QPT];
+        if (tile.whole) {  // block-uniform
+#pragma unroll
+            for (int k = 0; k < FE_QPT; k++) pretest(k, false, r01[k], r23[k]);
+        } else {
+            // a wave's two rows of quad k are y0 + 16 k + 2 * wave (+1): skipped when both lie outside the margin
+            const int wrow = y0 + 2 * __builtin_amdgcn_readfirstlane(wave);
+            const bool xin = x0 < width - margin && x0 + FE_TW > margin;  // some column of the tile is inside
+#pragma unroll
+            for (int k = 0; k < FE_QPT; k++) {
+                const int yw = wrow + 16 * k;
+                r01[k] = r23[k] = 0;
+                if (xin && yw + 1 >= margin && yw < height - margin) pretest(k, true, r01[k], r23[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FE_QPT; k++) {
+            pass[4 * k + 0] = (r01[k] & 0xffffu) != 0; pass[4 * k + 1] = r01[k] > 0xffffu;
+            pass[4 * k + 2] = (r23[k] & 0xffffu) != 0; pass[4 * k + 3] = r23[k] > 0xffffu;
         }
         // ... and the 1-px rim around the tile (one pixel per thread of the first waves)
         int hr = -1, hc = 0;
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
             hr = horiz ? (top ? 3 : 4 + FE_TH) : 4 + side;
             hc = horiz ? 3 + tid - (top ? 0 : FE_TW + 2) : (left ? 3 : 4 + FE_TW);
             const int ix = x0 - 4 + hc, iy = y0 - 4 + hr;
-            bool ok = ix >= 3 && ix < width - 3 && iy >= 3 && iy < height - 3;
+            bool ok = ix >= margin && ix < width - margin && iy >= margin && iy < height - margin;
             if (ok) {
                 const uint8_t *p = &s_gray[hr * FE_PITCH + hc];
                 ok = fast_quick(p[0], p[3 * FE_PITCH], p[-3 * FE_PITCH], p[3], p[-3], thr);
@@ -667,7 +689,7 @@ extern "C" int vo_debug_fe_stamps(unsigned long long *out)
 
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
                      int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
-                     uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s)
+                     uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s, int margin)
 {
     // block b serves XCD group b % 8, which owns the tile columns congruent to
     // b % 8; the grid holds the largest group's tile count for every group
@@ -676,15 +698,16 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     // floor(col / tiles_x) == umulhi(col, inv) for col * tiles_x < 2^32
     const uint32_t inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
+    margin = margin < 3 ? 3 : margin;  // cv::FAST itself never evaluates the outer 3 pixels
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
 }
 
 // ---------------------------------------------------------------- select

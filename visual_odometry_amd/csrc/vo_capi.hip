@@ -717,12 +717,13 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
     auto level = [&](uint8_t *base, int l) { return PlaneBatch{base + orb.lv[l].off, orb.lv[l].pitch, orb.frame_bytes}; };
     auto fast_level = [&](int l) {
         const OrbLevel &L = orb.lv[l];
-        // level 0 converts to gray on the way in and keeps the gray plane for the pyramid
+        // level 0 converts to gray on the way in and keeps the gray plane for the pyramid; corners closer than
+        // kFBorder to the edge are dropped by the selection, so only their inner neighbours' scores are needed
         const uint8_t *in = l == 0 ? src : d_pyr + L.off;
         launch_frontend(in, L.w, L.h, l == 0 ? src_stride : L.pitch, l == 0 ? src_frame_stride : orb.frame_bytes,
                         l == 0 ? channels : 1, l == 0 ? level(d_pyr, 0) : PlaneBatch{nullptr, 0, 0},
                         PlaneBatch{nullptr, 0, 0}, level(d_pyr_blur, l), fast_threshold, d_orb_cand + L.cand_off,
-                        d_orb_cand_count + L.count_off, batch, gc, stream);
+                        d_orb_cand_count + L.count_off, batch, gc, stream, kFBorder - 1);
     };
     fast_level(0);
     mark(1);

@@ -89,12 +89,15 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride,
 // cand[(f*T + t)*kTileCap ...] as keys ((255-score) << 24) | (y*width + x) and
 // their number to tile_count[f*T + t] (no initialisation needed).
 // Any of gray_out/score/blur may have base == 0, cand may be null; `score`
-// receives the per-pixel score map (diagnostic).
+// receives the per-pixel score map (diagnostic).  Corners are looked for at
+// least `margin` px inside the image (cv::FAST: 3); a caller that drops a
+// border of b px afterwards may pass b - 1 (the neighbours of a kept corner
+// still get their scores).
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
                      size_t src_frame_stride, int channels, PlaneBatch gray_out,
                      PlaneBatch score, PlaneBatch blur, int threshold,
                      uint32_t *cand, uint32_t *tile_count, int batch,
-                     GrayCoeffs c, hipStream_t s);
+                     GrayCoeffs c, hipStream_t s, int margin = 3);
 
 // Keep the max_features best keys per frame (all of them, in raster order,
 // when there are not more than max_features), drop keypoints closer than
