@@ -214,6 +214,26 @@ def test_detect_orb_bit_exact(ctx, oracle, cam_name, nfeatures, levels, scale):
     assert len(np.unique(k["octave"])) == levels
 
 
+@pytest.mark.parametrize("shape,levels", [((289, 514), 3), ((95, 200), 4), ((97, 131), 2), ((600, 1067), 2),
+                                          ((201, 357), 3), ((64, 190), 2), ((63, 300), 1), ((321, 159), 4)])
+def test_detect_orb_odd_sizes(ctx, oracle, shape, levels):
+    """Frames whose last tile column or row is almost empty, and levels with only a few rows (or none) inside the
+    31-px border the detector drops: same key points and descriptors as the oracle."""
+    h, w = shape
+    big = synth.make_sequence(synth.CONFIG_CAMERAS["hd720"], 1, seed=h + w, channels=1)["frames"][0]
+    g = np.ascontiguousarray(big[40:40 + h, 100:100 + w])
+    k_ref, d_ref, lv, bl = oracle.orb_detect(g, 600, 1.2, levels, 20, pyramid=True)
+    k, d = ctx.detect_orb(g, 600, 1.2, levels, 20)
+    for l in range(levels):
+        assert np.array_equal(ctx.orb_level(0, l), lv[l]), f"pyramid level {l}"
+        assert np.array_equal(ctx.orb_level(0, l, blurred=True), bl[l]), f"blurred level {l}"
+    assert len(k) == len(k_ref)
+    assert np.array_equal(_kp_bits(k), _kp_bits(k_ref))
+    assert np.array_equal(d, d_ref)
+    if min(h, w) > 150:
+        assert len(k) > 100
+
+
 def test_detect_orb_flat_and_tiny(ctx, oracle):
     flat = np.full((120, 160), 90, np.uint8)
     k, d = ctx.detect_orb(flat, 500, 1.2, 8, 20)
