@@ -31,8 +31,8 @@ raw = C.CDLL(capi.LIB_PATH)
 raw.vo_debug_os_stamps.argtypes = [C.c_void_p]
 assert raw.vo_debug_os_stamps(out.ctypes.data) == 0
 names = ["flatten tile lists", "border filter + score histogram", "cut score (scan)", "gather survivors",
-         "Harris responses", "radix select (4 passes)", "second cut (compaction)", "bitonic sort by raster index",
-         "write level list"]
+         "Harris responses", "radix select (4 passes)", "second cut (compaction)", "pad the list",
+         "rank by counting + write level list"]
 t = out[:, :, :10].astype(np.int64)
 d = np.diff(t, axis=2)
 for lvl in (0, 3, 7):

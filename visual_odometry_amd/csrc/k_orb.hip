@@ -131,30 +131,67 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
 constexpr int OS_THREADS = 1024;
 constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level
 
-// HarrisResponses(): 7x7 block, k = 0.04, Sobel-like integer gradients
+typedef short ss2 __attribute__((ext_vector_type(2)));
+
+// HarrisResponses(): 7x7 block, k = 0.04, Sobel-like integer gradients.  The
+// three sums are integers, so the order of evaluation is free: the nine rows of
+// the 9x9 footprint come in as three aligned dwords each (12 line accesses per
+// key point instead of 81 byte gathers -- the ranking kernel is bound by those),
+// are unpacked to pairs of 16-bit values and the gradients and their products
+// are formed two columns at a time (packed 16-bit adds, v_dot2_i32_i16).
+// Requires pitch % 4 == 0 and img 4-byte aligned.
 __device__ __forceinline__ float harris_response(const uint8_t *img, int pitch, int x0, int y0)
 {
-    // rows y0-4 .. y0+4, columns x0-4 .. x0+4; gradients need a sliding 3-row window
-    int a = 0, b = 0, c = 0;
-    const uint8_t *base = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
-    int up[9], mid[9], dn[9];
+    const size_t off = (size_t)(y0 - 4) * pitch + (size_t)(x0 - 4);
+    const uint32_t r = (uint32_t)off & 3u;  // byte of column x0 - 4 in its dword
+    const uint8_t *pa = img + (off & ~(size_t)3);
+    uint32_t raw[9][3];
 #pragma unroll
-    for (int j = 0; j < 9; j++) { up[j] = base[j]; mid[j] = base[pitch + j]; }
+    for (int k = 0; k < 9; k++) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(pa + (size_t)k * pitch);
+        raw[k][0] = q[0]; raw[k][1] = q[1]; raw[k][2] = q[2];
+    }
+    // row k as five pairs of 16-bit values: columns (0,1) (2,3) (4,5) (6,7) (8,-)
+    auto unpack = [&](int k, uint32_t P[5]) {
+        const uint32_t n0 = __builtin_amdgcn_alignbyte(raw[k][1], raw[k][0], r);
+        const uint32_t n1 = __builtin_amdgcn_alignbyte(raw[k][2], raw[k][1], r);
+        const uint32_t n2 = __builtin_amdgcn_alignbyte(0u, raw[k][2], r);
+        P[0] = __builtin_amdgcn_perm(0u, n0, 0x0c010c00u); P[1] = __builtin_amdgcn_perm(0u, n0, 0x0c030c02u);
+        P[2] = __builtin_amdgcn_perm(0u, n1, 0x0c010c00u); P[3] = __builtin_amdgcn_perm(0u, n1, 0x0c030c02u);
+        P[4] = n2 & 0xffu;
+    };
+    uint32_t U[5], M[5], D[5];
+    unpack(0, U);
+    unpack(1, M);
+    int a = 0, b = 0, c = 0;
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const uint8_t *row = base + (size_t)(i + 2) * pitch;
+        unpack(i + 2, D);
+        // s = up + 2 mid + dn (horizontal gradient: s[j+1] - s[j-1]); d = dn - up (vertical: d[j-1] + 2 d[j] + d[j+1])
+        ss2 S[5], V[5];
 #pragma unroll
-        for (int j = 0; j < 9; j++) dn[j] = row[j];
-#pragma unroll
-        for (int j = 1; j <= 7; j++) {
-            const int ix = (mid[j + 1] - mid[j - 1]) * 2 + (up[j + 1] - up[j - 1]) + (dn[j + 1] - dn[j - 1]);
-            const int iy = (dn[j] - up[j]) * 2 + (dn[j - 1] - up[j - 1]) + (dn[j + 1] - up[j + 1]);
-            a += ix * ix;
-            b += iy * iy;
-            c += ix * iy;
+        for (int k = 0; k < 5; k++) {
+            const ss2 u = __builtin_bit_cast(ss2, U[k]), m = __builtin_bit_cast(ss2, M[k]), d = __builtin_bit_cast(ss2, D[k]);
+            S[k] = u + m + m + d;
+            V[k] = d - u;
         }
 #pragma unroll
-        for (int j = 0; j < 9; j++) { up[j] = mid[j]; mid[j] = dn[j]; }
+        for (int k = 0; k < 4; k++) {
+            // columns 2k+1, 2k+2
+            ss2 ix = S[k + 1] - S[k];
+            const ss2 e = __builtin_bit_cast(
+                ss2, __builtin_amdgcn_alignbyte(__builtin_bit_cast(uint32_t, V[k + 1]), __builtin_bit_cast(uint32_t, V[k]), 2));
+            ss2 iy = V[k] + e + e + V[k + 1];
+            if (k == 3) {  // column 8 is outside the 7x7 block
+                ix = __builtin_bit_cast(ss2, __builtin_bit_cast(uint32_t, ix) & 0xffffu);
+                iy = __builtin_bit_cast(ss2, __builtin_bit_cast(uint32_t, iy) & 0xffffu);
+            }
+            a = __builtin_amdgcn_sdot2(ix, ix, a, false);
+            b = __builtin_amdgcn_sdot2(iy, iy, b, false);
+            c = __builtin_amdgcn_sdot2(ix, iy, c, false);
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { U[k] = M[k]; M[k] = D[k]; }
     }
     const float scale = 1.f / ((1 << 2) * 7 * 255.f);
     const float scale_sq_sq = scale * scale * scale * scale;
@@ -202,7 +239,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __shared__ uint32_t s_buf[2 * OS_K1CAP];
     __shared__ uint32_t s_scan[OS_THREADS];
     uint32_t *const s_ras = s_buf, *const s_key = s_buf + OS_K1CAP;
-    __shared__ uint32_t s_oras[kOrbLevelCap];
+    __shared__ __attribute__((aligned(16))) uint32_t s_oras[kOrbLevelCap];
     __shared__ uint32_t s_okey[kOrbLevelCap];
     __shared__ uint32_t s_hist[256];
     __shared__ int s_cut, s_n1, s_n2, s_remaining;
@@ -317,29 +354,21 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __syncthreads();
     const int K2 = min(s_n2, kOrbLevelCap);
     OS_STAMP(7);
-    int n_pow2 = 1;
-    while (n_pow2 < K2) n_pow2 <<= 1;
-    for (int i = K2 + tid; i < n_pow2; i += OS_THREADS) s_oras[i] = 0xffffffffu;
+    // raster order by counting: the rank of a survivor is the number of survivors with a smaller raster index
+    // (all distinct); every lane of a wave reads the same four entries per step (LDS broadcast)
+    for (int i = K2 + tid; i < ((K2 + 3) & ~3); i += OS_THREADS) s_oras[i] = 0xffffffffu;
     __syncthreads();
-    for (int k = 2; k <= n_pow2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < n_pow2 / 2; t += OS_THREADS) {
-                const int i = ((t / j) * 2 * j) + (t % j), p = i + j;
-                const bool up = (i & k) == 0;
-                const uint32_t a = s_oras[i], b = s_oras[p];
-                if ((a > b) == up) {
-                    s_oras[i] = b; s_oras[p] = a;
-                    const uint32_t ka = s_okey[i];
-                    s_okey[i] = s_okey[p]; s_okey[p] = ka;
-                }
-            }
-            __syncthreads();
-        }
     OS_STAMP(8);
     const size_t o = ((size_t)f * plan.nlevels + l) * kOrbLevelCap;
     for (int i = tid; i < K2; i += OS_THREADS) {
-        lvl_ras[o + i] = s_oras[i];
-        lvl_resp[o + i] = key_to_float(s_okey[i]);
+        const uint32_t me = s_oras[i];
+        int rank = 0;
+        for (int j = 0; j < K2; j += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_oras[j]);
+            rank += (int)(v.x < me) + (int)(v.y < me) + (int)(v.z < me) + (int)(v.w < me);
+        }
+        lvl_ras[o + rank] = me;
+        lvl_resp[o + rank] = key_to_float(s_okey[i]);
     }
     OS_STAMP(9);
     if (tid == 0) lvl_n[f * plan.nlevels + l] = K2;

@@ -266,10 +266,25 @@ __device__ inline int flatten_tile_lists(const uint32_t *__restrict__ cand, cons
     __syncthreads();
     const uint32_t total = s_total;
     const int lane = tid & 63;
-    for (int t = tid >> 6; t < ntiles; t += THREADS / 64) {
-        const uint32_t o = s_off[t];
-        const uint32_t n = (t + 1 < ntiles ? s_off[t + 1] : total) - o;
-        for (uint32_t j = lane; j < n; j += 64) flat[o + j] = cand[(size_t)t * kTileCap + j];
+    // a wave copies four tiles per step: the first 64 keys of each are loaded (at a clamped index, so the loads
+    // need no guard and are all in flight together) before any is stored; longer lists finish in a tail loop
+    constexpr int WAVES = THREADS / 64, U = 4;
+    for (int t = tid >> 6; t < ntiles; t += WAVES * U) {
+        uint32_t v[U], o[U], n[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int tt = min(t + u * WAVES, ntiles - 1);
+            o[u] = s_off[tt];
+            n[u] = t + u * WAVES < ntiles ? (tt + 1 < ntiles ? s_off[tt + 1] : total) - o[u] : 0u;
+            v[u] = cand[(size_t)tt * kTileCap + min((uint32_t)lane, max(n[u], 1u) - 1u)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if ((uint32_t)lane < n[u]) flat[o[u] + lane] = v[u];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            for (uint32_t j = lane + 64; j < n[u]; j += 64)
+                flat[o[u] + j] = cand[(size_t)min(t + u * WAVES, ntiles - 1) * kTileCap + j];
     }
     __threadfence_block();
     __syncthreads();
