@@ -383,7 +383,7 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
 //      meanwhile (4-byte dot products, two rows per task);
 //   3. 3x3 strict non-max suppression (cv::FAST, nonmaxSuppression = true) of
 //      the queued corners; survivors go straight to the tile's slot list in
-//      global memory as keys ((255-score) << 24) | raster index (slots from an
+//      global memory as keys ((255-score) << 24) | y << 12 | x (slots from an
 //      LDS counter; the wave that finishes last stores the tile's count -- no
 //      global atomics, no zero-initialised counters).  The other waves run the
 //      Gaussian's column pass (2-element dot products over row pairs).
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                     const uint32_t n0 = umax3(sp[-FE_PITCH - 1], sp[-FE_PITCH], sp[-FE_PITCH + 1]);
                     const uint32_t n1 = umax3(sp[FE_PITCH - 1], sp[FE_PITCH], sp[FE_PITCH + 1]);
                     is_max = sc > umax3(n0, n1, max((uint32_t)sp[-1], (uint32_t)sp[1]));  // implies sc != 0
-                    key = ((255u - sc) << 24) | (uint32_t)((y0 - 4 + r) * width + (x0 - 4 + cc));
+                    key = corner_key(sc, x0 - 4 + cc, y0 - 4 + r);
                 }
             }
             const uint64_t mm = __ballot(is_max);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
         const uint32_t cb = (uint32_t)s_cut_bin;
         for (int i = tid; i < M; i += SEL_THREADS) {
             const uint32_t k = c[i];
-            if ((k >> 24) == cb) atomicAdd(&s_rows[(k & 0xffffffu) / (uint32_t)width], 1u);
+            if ((k >> 24) == cb) atomicAdd(&s_rows[key_y(k)], 1u);
         }
         __syncthreads();
         {
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
                 key = ((k & 0xffffffu) << 8) | (k >> 24);  // raster order
             } else {
                 const uint32_t b = k >> 24;
-                take = b < cb || (b == cb && (k & 0xffffffu) / (uint32_t)width <= cr);
+                take = b < cb || (b == cb && (uint32_t)key_y(k) <= cr);
                 key = k;
             }
             if (take) {
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
     int cnt = 0;
     for (int i = begin; i < end; i++) {
         const uint32_t key = s_keys[i];
-        const uint32_t raster = all ? key >> 8 : key & 0xffffffu;
-        const int yy = raster / (uint32_t)width, xx = raster - yy * width;
+        const uint32_t pos = all ? key >> 8 : key;
+        const int yy = key_y(pos), xx = key_x(pos);
         cnt += (size_ok && xx >= border && xx < width - border && yy >= border && yy < height - border);
     }
     const uint32_t inc_cnt = block_scan_inclusive<SEL_THREADS>((uint32_t)cnt, s_scan);
@@ -850,9 +850,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
     vo_kp *o = kps + (size_t)f * kp_stride;
     for (int i = begin; i < end; i++) {
         const uint32_t key = s_keys[i];
-        const uint32_t raster = all ? key >> 8 : key & 0xffffffu;
+        const uint32_t pos = all ? key >> 8 : key;
         const uint32_t sc = 255u - (all ? key & 255u : key >> 24);
-        const int yy = raster / (uint32_t)width, xx = raster - yy * width;
+        const int yy = key_y(pos), xx = key_x(pos);
         if (size_ok && xx >= border && xx < width - border && yy >= border && yy < height - border) {
             vo_kp kp;
             kp.x = (float)xx; kp.y = (float)yy; kp.size = 7.f; kp.angle = -1.f;

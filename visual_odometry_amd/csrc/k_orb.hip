@@ -265,8 +265,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __syncthreads();
 
     // 1. border filter + FAST-score histogram
-    auto in_border = [&](uint32_t ras) {
-        const int y = ras / (uint32_t)w, x = ras - y * w;
+    auto in_border = [&](uint32_t pos) {
+        const int y = key_y(pos), x = key_x(pos);
         return x >= border && x < w - border && y >= border && y < h - border;
     };
     if (size_ok)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     // 3. Harris response of each survivor
     for (int i = tid; i < K1; i += OS_THREADS) {
         const uint32_t ras = s_ras[i];
-        const int y = ras / (uint32_t)w, x = ras - y * w;
+        const int y = key_y(ras), x = key_x(ras);
         s_key[i] = ordered_key(harris_response(img, L.pitch, x, y));
     }
     __syncthreads();
@@ -407,21 +407,36 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 constexpr int OF_THREADS = 256;
+constexpr int OF_LANES = 8;                        // lanes per keypoint
+constexpr int OF_KPB = OF_THREADS / OF_LANES;      // keypoints per block
 
-// 32 lanes per output keypoint: concatenates the levels' survivors (level by
+// 8 lanes per output keypoint: concatenates the levels' survivors (level by
 // level), computes the intensity-centroid angle over the radius-15 disc of
 // the keypoint's level image (ICAngles()) and writes the cv::KeyPoint with
 // pt scaled to level-0 coordinates, size = 31 * scale, octave = level.
-// Lanes 0..30 of the group own the 31 columns u = -15..15; the 31 row loads of
-// a lane are all issued before the first use.
+// Lane q of a group owns the four columns u = -15 + 4q .. -12 + 4q (the last
+// one, u = 16, is masked): one unaligned dword per row, all 31 issued before
+// the first use; the disc is applied as a byte mask per |v| (table in LDS) and
+// the moments are formed with 4-byte dot products:
+//   m10 = sum u I = sum (u + 16) I - 16 sum I,   m01 = sum_v v (S(+v) - S(-v)).
 __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const uint8_t *__restrict__ pyr,
                                                           const uint32_t *__restrict__ lvl_ras,
                                                           const float *__restrict__ lvl_resp,
                                                           const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
                                                           int kp_stride, int *__restrict__ nkp)
 {
-    const int f = blockIdx.y, gl = threadIdx.x & 31;
-    const int i = blockIdx.x * (OF_THREADS / 32) + (threadIdx.x >> 5);
+    __shared__ uint32_t s_mask[16][OF_LANES];
+    const int f = blockIdx.y, gl = threadIdx.x & (OF_LANES - 1);
+    const int i = blockIdx.x * OF_KPB + (threadIdx.x >> 3);
+    if (threadIdx.x < 16 * OF_LANES) {
+        // byte j of s_mask[v][q]: column u = -15 + 4q + j lies inside the disc at row |v|
+        const int v = threadIdx.x >> 3, q = threadIdx.x & 7;
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (abs(-15 + 4 * q + j) <= kUmaxC(v)) m |= 0xffu << (8 * j);
+        s_mask[v][q] = m;
+    }
     int level = -1, j = 0, total = 0;
     for (int l = 0; l < plan.nlevels; l++) {
         const int n = lvl_n[f * plan.nlevels + l];
@@ -432,39 +447,49 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
     if (blockIdx.x == 0 && threadIdx.x == 0) nkp[f] = total;
     const bool live = level >= 0 && i < total;
     const int lv = live ? level : 0;
-    const int Lw = plan.lv[lv].w, Lpitch = plan.lv[lv].pitch;
+    const int Lpitch = plan.lv[lv].pitch;
     const float Lscale = plan.lv[lv].scale;
     const size_t Loff = plan.lv[lv].off;
     const size_t o = ((size_t)f * plan.nlevels + lv) * kOrbLevelCap + (live ? j : 0);
-    const uint32_t ras = live ? lvl_ras[o] : (uint32_t)(15 * Lw + 15);
-    const int y = ras / (uint32_t)Lw, x = ras - y * Lw;
+    const uint32_t ras = live ? lvl_ras[o] : 0u;
+    const int y = key_y(ras), x = key_x(ras);
     // block-uniform base + 32-bit offsets (a frame's pyramid is far below 4 GB): one add per row
     const uint8_t *frame = pyr + (size_t)f * plan.frame_bytes;
 
-    const int u = min(gl - 15, 15);  // lane 31 of the group repeats column 15 and is masked below
-    const int au = gl == 31 ? 16 : abs(u);
-    uint32_t off = (uint32_t)Loff + (uint32_t)(y - 15) * (uint32_t)Lpitch + (uint32_t)(x + u);
-    int val[31];
+    // the lane's last byte (u = 16 for q = 7) may lie one past the patch: rows are padded, the byte is masked
+    // (idle groups re-read the first bytes of the frame)
+    uint32_t off = live ? (uint32_t)Loff + (uint32_t)(y - 15) * (uint32_t)Lpitch + (uint32_t)(x - 15 + 4 * gl) : 0u;
+    const uint32_t step = live ? (uint32_t)Lpitch : 0u;
+    uint32_t val[31];
 #pragma unroll
     for (int k = 0; k < 31; k++) {
-        val[k] = frame[off];
-        off += (uint32_t)Lpitch;
+        __builtin_memcpy(&val[k], frame + off, 4);  // unaligned dword
+        off += step;
     }
-    // m10 = sum u * I, m01 = sum v * I over the disc: rows +v and -v share their half-width, so each pair is
-    // masked once, with its sum feeding m10 (times u at the end) and its difference m01
-    int sum = au <= kUmaxC(0) ? val[15] : 0, m01 = 0;
+    __syncthreads();
+    // weights u + 16 of the lane's four columns (1 .. 32)
+    const uint32_t w0 = (uint32_t)(1 + 4 * gl);
+    const uint32_t wts = w0 | ((w0 + 1) << 8) | ((w0 + 2) << 16) | ((w0 + 3) << 24);
+    const uint32_t c = val[15] & s_mask[0][gl];
+    uint32_t accw = __builtin_amdgcn_udot4(c, wts, 0u, false);
+    uint32_t acc1 = __builtin_amdgcn_udot4(c, 0x01010101u, 0u, false);
+    int m01 = 0;
 #pragma unroll
     for (int v = 1; v <= 15; v++) {
-        const bool in = au <= kUmaxC(v);
-        const int a = val[15 + v], b = val[15 - v];
-        sum += in ? a + b : 0;
-        m01 += v * (in ? a - b : 0);
+        const uint32_t m = s_mask[v][gl];
+        const uint32_t a = val[15 + v] & m, b = val[15 - v] & m;
+        accw = __builtin_amdgcn_udot4(a, wts, accw, false);
+        accw = __builtin_amdgcn_udot4(b, wts, accw, false);
+        const uint32_t sa = __builtin_amdgcn_udot4(a, 0x01010101u, 0u, false);
+        const uint32_t sb = __builtin_amdgcn_udot4(b, 0x01010101u, 0u, false);
+        acc1 += sa + sb;
+        m01 += v * ((int)sa - (int)sb);
     }
-    int m10 = u * sum;
+    int m10 = (int)accw - 16 * (int)acc1;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
+    for (int sh = OF_LANES / 2; sh > 0; sh >>= 1) {
+        m10 += __shfl_xor(m10, sh);
+        m01 += __shfl_xor(m01, sh);
     }
     if (live && gl == 0) {
         vo_kp kp;
@@ -662,7 +687,7 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
                        const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s)
 {
-    dim3 grid((kp_stride + OF_THREADS / 32 - 1) / (OF_THREADS / 32), batch);
+    dim3 grid((kp_stride + OF_KPB - 1) / OF_KPB, batch);
     hipLaunchKernelGGL(k_orb_finish, grid, dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras, lvl_resp, lvl_n, kps,
                        kp_stride, nkp);
 }

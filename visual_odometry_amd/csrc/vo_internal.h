@@ -86,7 +86,7 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride,
 // Fused tile kernel: (optional BGR[A]->gray) + FAST-9/16 with 3x3 strict
 // non-max suppression + 7x7 fixed-point Gaussian.  With T = tiles_of(width,
 // height), tile t of frame f writes its surviving corners to
-// cand[(f*T + t)*kTileCap ...] as keys ((255-score) << 24) | (y*width + x) and
+// cand[(f*T + t)*kTileCap ...] as keys ((255-score) << 24) | y << 12 | x and
 // their number to tile_count[f*T + t] (no initialisation needed).
 // Any of gray_out/score/blur may have base == 0, cand may be null; `score`
 // receives the per-pixel score map (diagnostic).  Corners are looked for at
@@ -217,6 +217,16 @@ void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const 
                     hipStream_t s);
 
 #ifdef __HIPCC__
+// Corner keys: (255 - score) << 24 | y << 12 | x.  Ascending key order is score descending, then raster order
+// (frames are at most kMaxDim = 4096 wide and high, so x and y take 12 bits each).
+static_assert(kMaxDim <= 4096, "corner keys hold 12-bit coordinates");
+__device__ __forceinline__ uint32_t corner_key(uint32_t score, int x, int y)
+{
+    return ((255u - score) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+}
+__device__ __forceinline__ int key_x(uint32_t k) { return (int)(k & 0xfffu); }
+__device__ __forceinline__ int key_y(uint32_t k) { return (int)((k >> 12) & 0xfffu); }
+
 // Inclusive prefix sum of one value per thread over the whole block (THREADS a
 // multiple of 64, at most 1024): wave scans by shuffles, then the waves'
 // totals.  s_part: LDS scratch for THREADS / 64 words.  Every thread of the
