@@ -1,8 +1,10 @@
 #!/bin/bash
-# A/B two builds of the library on one GPU box: tools/ab_run.sh <lib_a> <lib_b> [bench flags]
-a=$1; b=$2; shift 2
+# A/B builds of the library on one GPU box: tools/ab_run.sh <lib_a> <lib_b> [<lib_c> ...] [-- bench flags]
+libs=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do libs+=("$1"); shift; done
+[ "$1" == "--" ] && shift
 for i in 1 2; do
-  for l in "$a" "$b"; do
+  for l in "${libs[@]}"; do
     timeout -k 10 100 python tools/ab_bench.py "$l" --cpu-workers 0 --cpu-frames 0 "$@" > /tmp/ab.json 2>/tmp/ab.err || { tail -n 5 /tmp/ab.err; exit 1; }
     python - "$l" <<'PY'
 import json, sys

@@ -511,6 +511,12 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
 // The pattern's largest radius is 18.4 px, so every rotated sample lies within
 // +-18 px: the 37 x 37 patch is staged in LDS with dword loads first.
 constexpr int BS_R = 18;
+// low 24 bits of the float 1.5 * 2^23 + n are 0x400000 + n
+constexpr int kBriefRoundBias = 0x400000;
+__device__ __forceinline__ int brief_round_bits(float v)
+{
+    return (int)(__float_as_uint(v + 12582912.f) & 0xffffffu);
+}
 constexpr int BS_PWD = (2 * BS_R + 1 + 3 + 3) / 4;
 __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8_t *__restrict__ pyr_blur,
                                                       const vo_kp *__restrict__ kps, int kp_stride,
@@ -542,34 +548,44 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
         const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int x_al = (cx - BS_R) & ~3;  // keypoints are >= 31 px inside their level: never negative
         col0 = cx - x_al;
-        const uint8_t *src = pyr_blur + (size_t)f * plan.frame_bytes + L.off + (size_t)(cy - BS_R) * L.pitch + x_al;
-        // all of a lane's loads are issued before the first LDS write (lanes past the end re-read the last dword)
-        constexpr int N = (2 * BS_R + 1) * BS_PWD, PER = (N + 31) / 32;
+        // block-uniform base + 32-bit offsets (a frame's pyramid is far below 4 GB).  The group's 32 lanes cover
+        // two rows of 16 dwords per step (11 of the 16 are patch columns, the others repeat the last one and are
+        // not stored): one add per load, and all loads are issued before the first LDS write
+        const uint8_t *frame = pyr_blur + (size_t)f * plan.frame_bytes;
+        constexpr int ROWS = 2 * BS_R + 1, PER = (ROWS + 1) / 2;
+        const int rh = byte >> 4, c = min(byte & 15, BS_PWD - 1);
+        const bool col_ok = (byte & 15) < BS_PWD;
+        uint32_t off = (uint32_t)L.off + __umul24((uint32_t)(cy - BS_R + rh), (uint32_t)L.pitch) + (uint32_t)(x_al + 4 * c);
+        const uint32_t step = 2u * (uint32_t)L.pitch;
         uint32_t v[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int i = min(byte + 32 * u, N - 1);
-            const int r = i / BS_PWD, c = i - r * BS_PWD;
-            v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * c);
+            // the last step has a single row: the upper half of the group re-reads it
+            if (u == PER - 1 && (ROWS & 1)) off -= rh ? (uint32_t)L.pitch : 0u;
+            v[u] = *reinterpret_cast<const uint32_t *>(frame + off);
+            off += step;
         }
 #pragma unroll
         for (int u = 0; u < PER; u++)
-            if (byte + 32 * u < N) s_patch[g][byte + 32 * u] = v[u];
+            if (col_ok && 2 * u + rh < ROWS) s_patch[g][(2 * u + rh) * BS_PWD + c] = v[u];
     }
     __syncthreads();
     if (!live) return;
     const float a = s_cs[g][0], b = s_cs[g][1];
-    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0;
+    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0 -
+                            kBriefRoundBias * (BS_PWD * 4 + 1);
     const int8_t *p = s_pat + byte * 32;
     uint32_t val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const float x0 = (float)p[4 * t + 0], y0 = (float)p[4 * t + 1];
         const float x1 = (float)p[4 * t + 2], y1 = (float)p[4 * t + 3];
-        const int ix0 = __float2int_rn(x0 * a - y0 * b), iy0 = __float2int_rn(x0 * b + y0 * a);
-        const int ix1 = __float2int_rn(x1 * a - y1 * b), iy1 = __float2int_rn(x1 * b + y1 * a);
-        const int t0 = center[iy0 * (BS_PWD * 4) + ix0];
-        const int t1 = center[iy1 * (BS_PWD * 4) + ix1];
+        // cvRound by adding 1.5 * 2^23: the sum's low mantissa bits hold the coordinate rounded to nearest even
+        // (|coordinate| < 2^22); the bias of the bit patterns is taken off the base address once
+        const int ix0 = brief_round_bits(x0 * a - y0 * b), iy0 = brief_round_bits(x0 * b + y0 * a);
+        const int ix1 = brief_round_bits(x1 * a - y1 * b), iy1 = brief_round_bits(x1 * b + y1 * a);
+        const int t0 = center[__mul24(iy0, BS_PWD * 4) + ix0];
+        const int t1 = center[__mul24(iy1, BS_PWD * 4) + ix1];
         val |= (uint32_t)(t0 < t1) << t;
     }
     desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
