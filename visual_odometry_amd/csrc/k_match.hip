@@ -1,27 +1,19 @@
-// Matching kernels for gfx950: brute-force Hamming kNN-2 over LDS-staged
-// descriptor tiles (XOR + v_bcnt_u32_b32), merge + Lowe ratio test with
-// ordered compaction.  Integer work only; results are bit-exact.
+// Matching kernels for gfx950: brute-force Hamming kNN-2 on the matrix cores
+// (descriptor bits as int8 vectors, v_mfma_i32_32x32x32_i8), merge + Lowe ratio
+// test with ordered compaction.  Integer work only; results are bit-exact.
 #include "vo_internal.h"
 
 namespace vo {
 
-constexpr int KNN_THREADS = 128;
-constexpr int KNN_QPL = 2;                           // queries per lane
-constexpr int KNN_QPB = KNN_THREADS * KNN_QPL;       // queries per block
-constexpr int KNN_TILE = 128;                        // train descriptors per LDS tile
+constexpr int KNN_THREADS = 256;                 // four waves
+constexpr int KNN_QPW = 64;                      // queries per wave: two sets of 32 MFMA columns
+constexpr int KNN_QPB = (KNN_THREADS / 64) * KNN_QPW;  // queries per block
+constexpr int KNN_TILE = 32;                     // train descriptors per step (MFMA rows)
+constexpr int KNN_ROW = 256 + 16;                // bytes per unpacked train row in LDS: 16 consecutive rows of a
+                                                 // 16-byte read fall into distinct banks
 
-// Per query the two smallest keys are tracked, k0 <= k1, with
-// key = (distance << 16) | train index: the order is (distance, then lower
-// train index), the order in which cv::BFMatcher::knnMatch reports equal
-// distances (reference src/feature_matcher.cpp:27-31).
-// popcount(x) + acc in one instruction (v_bcnt_u32_b32); written out because the compiler otherwise
-// computes independent popcounts and adds them up with extra instructions
-__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
-{
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 // median of three unsigned values (v_med3_u32; the compiler has no builtin for the integer form)
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
@@ -31,13 +23,37 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// bits 4i .. 4i+3 of x as four bytes holding 0 or 1 (bit 4i+j in byte j): the multiplier puts bit j at position 8j
+__device__ __forceinline__ uint32_t nibble_bytes(uint32_t x, int i)
+{
+    return __umul24((x >> (4 * i)) & 15u, 0x204081u) & 0x01010101u;
+}
+
+// Brute-force Hamming kNN-2 on the matrix cores.  For descriptors as 0/1
+// vectors the distance is |q| + |t| - 2 <q, t>, so all pairs of a 32-train x
+// 32-query tile come out of eight v_mfma_i32_32x32x32_i8 (K = 256 bits as
+// bytes).  A block holds 256 queries in registers for its whole life (the MFMA
+// B operand, bytes 0 / -1, so the products accumulate -<q, t>) and streams the
+// trains of its share 32 at a time: the packed descriptors are expanded to
+// bytes 0 / 1 in LDS (double-buffered; the next tile's words are in flight
+// during the MFMAs) together with a word (|t| + 512) << 16 | train index per
+// train.  With the query on the lane (MFMA column) and 16 trains in a lane's
+// accumulator registers, the running two smallest keys of a query cost three
+// vector instructions per pair:
+//   key = (acc << 17) + word = (|t| + 512 - 2 <q, t>) << 16 | index,
+//   k1 = med3(k0, k1, key), k0 = min(k0, key);
+// |q| - 512 is added to the distance field at the end.  Keys order by
+// (distance, then lower train index), the order in which
+// cv::BFMatcher::knnMatch reports equal distances (reference
+// src/feature_matcher.cpp:27-31).  Integer arithmetic throughout: bit-exact.
 __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
                                                       const int *__restrict__ nkp,
                                                       const int *__restrict__ q_slot,
                                                       const int *__restrict__ t_slot, int kp_stride,
                                                       uint2 *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) uint4 s_tile[KNN_TILE * 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][KNN_TILE * KNN_ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[2][KNN_TILE];
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -46,59 +62,106 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
     const int qbase = blockIdx.x * KNN_QPB;
     if (qbase >= nq) return;
 
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;  // MFMA column (query) / row (train) and K half of this lane
     const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
-    const uint4 *td = reinterpret_cast<const uint4 *>(desc + ts * slot_stride);
+    const uint32_t *td = reinterpret_cast<const uint32_t *>(desc + ts * slot_stride);
 
-    uint4 qa[KNN_QPL], qb[KNN_QPL];
-    uint32_t k0[KNN_QPL], k1[KNN_QPL];
+    // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes 0 / -1
+    v4i B[2][8];
+    uint32_t fix[2], k0[2], k1[2];
 #pragma unroll
-    for (int i = 0; i < KNN_QPL; i++) {
-        const int q = min(qbase + i * KNN_THREADS + (int)threadIdx.x, nq - 1);
-        qa[i] = qd[2 * q];
-        qb[i] = qd[2 * q + 1];
-        k0[i] = k1[i] = 0xffffffffu;
+    for (int s = 0; s < 2; s++) {
+        const int q = min(qbase + wave * KNN_QPW + 32 * s + col, nq - 1);
+        const uint4 lo = qd[2 * q], hi = qd[2 * q + 1];
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t pq = 0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            pq += __popc(w[ks]);
+            const uint32_t bits = (w[ks] >> (16 * half)) & 0xffffu;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t m = nibble_bytes(bits, j);
+                B[s][ks][j] = (int)((m << 8) - m);  // 1 -> 0xff in every byte
+            }
+        }
+        fix[s] = (pq - 512u) << 16;
+        k0[s] = k1[s] = 0xffffffffu;
     }
 
     // this block's share of the train set: an even cut of the descriptors
     const int j_lo = (int)(((long long)nt * split) / kKnnSplits);
     const int j_hi = (int)(((long long)nt * (split + 1)) / kKnnSplits);
+    const int ntiles = (j_hi - j_lo + KNN_TILE - 1) / KNN_TILE;
 
-    for (int j0 = j_lo; j0 < j_hi; j0 += KNN_TILE) {
-        const int jn = min(KNN_TILE, j_hi - j0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < jn * 2; i += KNN_THREADS) s_tile[i] = td[2 * j0 + i];
-        __syncthreads();
-        auto one = [&](int j) {
-            const uint4 ta = s_tile[2 * j], tb = s_tile[2 * j + 1];  // wave-uniform: LDS broadcast
-            const uint32_t jj = (uint32_t)(j0 + j);
+    // staging role of this thread: word sc of train sr of the tile
+    const int sr = tid >> 3, sc = tid & 7;
+    auto load_packed = [&](int t) -> uint32_t {
+        const int j = j_lo + t * KNN_TILE + sr;
+        return td[(size_t)min(j, nt - 1) * 8 + sc] & (j < j_hi ? 0xffffffffu : 0u);  // rows past the share: all zero
+    };
+    auto stage = [&](int buf, int t, uint32_t x) {
+        uint4 a, b;
+        a.x = nibble_bytes(x, 0); a.y = nibble_bytes(x, 1); a.z = nibble_bytes(x, 2); a.w = nibble_bytes(x, 3);
+        b.x = nibble_bytes(x, 4); b.y = nibble_bytes(x, 5); b.z = nibble_bytes(x, 6); b.w = nibble_bytes(x, 7);
+        uint8_t *row = &s_a[buf][sr * KNN_ROW + 32 * sc];
+        *reinterpret_cast<uint4 *>(row) = a;
+        *reinterpret_cast<uint4 *>(row + 16) = b;
+        uint32_t p = __popc(x);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        const int j = j_lo + t * KNN_TILE + sr;
+        // rows past the share have all-zero bytes (accumulator 0) and the largest key
+        if (sc == 0) s_c[buf][sr] = j < j_hi ? ((p + 512u) << 16) | (uint32_t)j : 0xffffffffu;
+    };
+
+    if (ntiles > 0) stage(0, 0, load_packed(0));
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ntiles;  // block-uniform
+        uint32_t next = 0;
+        if (more) next = load_packed(t + 1);
+        v4i A[8];
 #pragma unroll
-            for (int i = 0; i < KNN_QPL; i++) {
-                // eight XOR + eight accumulating popcounts (the accumulation is chained on purpose)
-                uint32_t d = popc_acc(qa[i].x ^ ta.x, 0u);
-                d = popc_acc(qa[i].y ^ ta.y, d);
-                d = popc_acc(qa[i].z ^ ta.z, d);
-                d = popc_acc(qa[i].w ^ ta.w, d);
-                d = popc_acc(qb[i].x ^ tb.x, d);
-                d = popc_acc(qb[i].y ^ tb.y, d);
-                d = popc_acc(qb[i].z ^ tb.z, d);
-                d = popc_acc(qb[i].w ^ tb.w, d);
-                const uint32_t key = (d << 16) | jj;
-                // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
-                k1[i] = umed3(k0[i], k1[i], key);
-                k0[i] = min(k0[i], key);
-            }
-        };
-        int j = 0;
-        for (; j + 4 <= jn; j += 4) {
-            one(j); one(j + 1); one(j + 2); one(j + 3);
+        for (int ks = 0; ks < 8; ks++)
+            A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * half]);
+        // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
+        uint32_t cw[16];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_c[buf][8 * g + 4 * half]);
+            cw[4 * g] = v.x; cw[4 * g + 1] = v.y; cw[4 * g + 2] = v.z; cw[4 * g + 3] = v.w;
         }
-        for (; j < jn; j++) one(j);
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t key = ((uint32_t)acc[r] << 17) + cw[r];
+                // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
+                k1[s] = umed3(k0[s], k1[s], key);
+                k0[s] = min(k0[s], key);
+            }
+        }
+        if (more) stage(buf ^ 1, t + 1, next);
+        __syncthreads();
     }
 
 #pragma unroll
-    for (int i = 0; i < KNN_QPL; i++) {
-        const int q = qbase + i * KNN_THREADS + (int)threadIdx.x;
-        if (q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(k0[i], k1[i]);
+    for (int s = 0; s < 2; s++) {
+        // the other half of the wave holds the other 16 rows of every tile for the same query
+        const uint32_t o0 = __shfl_xor(k0[s], 32), o1 = __shfl_xor(k1[s], 32);
+        uint32_t n0 = min(k0[s], o0);
+        uint32_t n1 = min(max(k0[s], o0), min(k1[s], o1));
+        if (n0 != 0xffffffffu) n0 += fix[s];
+        if (n1 != 0xffffffffu) n1 += fix[s];
+        const int q = qbase + wave * KNN_QPW + 32 * s + col;
+        if (half == 0 && q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(n0, n1);
     }
 }
 
