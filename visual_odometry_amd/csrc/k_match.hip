@@ -105,9 +105,12 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         uint4 a, b;
         a.x = nibble_bytes(x, 0); a.y = nibble_bytes(x, 1); a.z = nibble_bytes(x, 2); a.w = nibble_bytes(x, 3);
         b.x = nibble_bytes(x, 4); b.y = nibble_bytes(x, 5); b.z = nibble_bytes(x, 6); b.w = nibble_bytes(x, 7);
+        // the two 16-byte halves of words 4 .. 7 are swapped, so that the eight lanes of a train write (and the
+        // MFMA operand reads below fetch) distinct banks
         uint8_t *row = &s_a[buf][sr * KNN_ROW + 32 * sc];
-        *reinterpret_cast<uint4 *>(row) = a;
-        *reinterpret_cast<uint4 *>(row + 16) = b;
+        const int sw = (sc >> 2) * 16;
+        *reinterpret_cast<uint4 *>(row + sw) = a;
+        *reinterpret_cast<uint4 *>(row + (16 - sw)) = b;
         uint32_t p = __popc(x);
         p += __shfl_xor(p, 1);
         p += __shfl_xor(p, 2);
@@ -117,9 +120,22 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         if (sc == 0) s_c[buf][sr] = j < j_hi ? ((p + 512u) << 16) | (uint32_t)j : 0xffffffffu;
     };
 
-    if (ntiles > 0) stage(0, 0, load_packed(0));
-    __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
+    // One step = one tile.  The two accumulation chains of a tile (query sets 0 and 1) are issued one after
+    // the other; the top-2 updates of a finished chain are placed in the issue gaps of the next chain (two
+    // accumulator registers = six vector instructions per MFMA), so set 1 of tile t-1 is consumed under chain 0
+    // of tile t and set 0 of tile t under chain 1 of tile t.  cwc / cwp: the train words of this / the previous
+    // tile (register sets alternate between steps).
+    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+    auto update2 = [&](int s, const v16i &acc, const uint32_t (&cw)[16], int r) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t key = ((uint32_t)acc[r + i] << 17) + cw[r + i];
+            // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
+            k1[s] = umed3(k0[s], k1[s], key);
+            k0[s] = min(k0[s], key);
+        }
+    };
+    auto step = [&](int t, uint32_t (&cwc)[16], const uint32_t (&cwp)[16]) {
         const int buf = t & 1;
         const bool more = t + 1 < ntiles;  // block-uniform
         uint32_t next = 0;
@@ -127,29 +143,48 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         v4i A[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ks++)
-            A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * half]);
+            A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
         // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
-        uint32_t cw[16];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_c[buf][8 * g + 4 * half]);
-            cw[4 * g] = v.x; cw[4 * g + 1] = v.y; cw[4 * g + 2] = v.z; cw[4 * g + 3] = v.w;
+            cwc[4 * g] = v.x; cwc[4 * g + 1] = v.y; cwc[4 * g + 2] = v.z; cwc[4 * g + 3] = v.w;
+        }
+        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[0][ks], ks == 0 ? zero : acc0, 0, 0, 0);
+            update2(1, acc1, cwp, 2 * ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < 8; ks++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t key = ((uint32_t)acc[r] << 17) + cw[r];
-                // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
-                k1[s] = umed3(k0[s], k1[s], key);
-                k0[s] = min(k0[s], key);
-            }
+        for (int ks = 0; ks < 8; ks++) {
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[1][ks], ks == 0 ? zero : acc1, 0, 0, 0);
+            update2(0, acc0, cwc, 2 * ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) stage(buf ^ 1, t + 1, next);
         __syncthreads();
+    };
+
+    if (ntiles > 0) stage(0, 0, load_packed(0));
+    __syncthreads();
+    uint32_t cwa[16], cwb[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) cwa[r] = cwb[r] = 0xffffffffu;  // with acc1 = 0: keys that change nothing
+    for (int t = 0; t < ntiles; t += 2) {
+        step(t, cwa, cwb);
+        if (t + 1 < ntiles) step(t + 1, cwb, cwa);
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) cwb[r] = cwa[r];  // the last tile's words, for the tail below
+        }
+    }
+    // set 1 of the last tile (cwb holds its words after an even or an odd number of tiles)
+    if (ntiles > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) update2(1, acc1, cwb, r);
     }
 
 #pragma unroll
