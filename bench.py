@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 VALU_PEAK_GLOPS = 39321.6    # 256 CU x 64 lanes x 2.4 GHz, 32-bit integer lane-ops/s (G)
+MFMA_I8_PEAK_TOPS = 5033.2   # dense int8 MFMA: 1024 SIMDs x 1024 MAC/clk x 2 x 2.4 GHz (twice the bf16 rate)
 
 
 def pingpong(n):
@@ -101,6 +102,9 @@ def main():
     ap.add_argument("--detector", choices=("orb", "fast"), default="orb",
                     help="orb: full ORB detector, 8-level pyramid; fast: FAST corners + ORB::compute on one "
                          "level, the sequence the reference node executes")
+    ap.add_argument("--matcher", choices=["mfma", "popcount"], default="mfma",
+                    help="kernel for the all-pairs Hamming distances: int8 matrix cores (default) or XOR + popcount "
+                         "on the vector ALU (identical results)")
     ap.add_argument("--cpu-frames", type=int, default=192, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=16,
                     help="host cores for the all-core CPU baseline (one stream each; 0 = skip; capped at the CPU count)")
@@ -146,6 +150,7 @@ def main():
     cap = args.features + (64 if levels else 0)  # room for boundary ties of the per-level ranking
     for _ in range(NC):
         c = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=Bc)
+        c.set_matcher(args.matcher)
         c.batch_configure(W, H, C, n_streams=S, frames_per_stream=F, max_features=args.features,
                           fast_threshold=20, camera=K, orb_levels=levels)
         ctxs.append(c)
@@ -210,8 +215,11 @@ def main():
             # levels 1..L-1: read the gray level, write its blurred version
             "frontend_upper_levels": ("hbm", Bc * 2 * px_up / 1e9, HBM_PEAK_GBS, "GB/s"),
             "brief": ("hbm", Bc * n_kp * (512 + 32) / 1e9, HBM_PEAK_GBS, "GB/s"),
-            # 8 XOR + 8 popcount-accumulate 32-bit lane operations per descriptor pair
-            "knn2": ("valu", Bc * n_kp * n_kp * 16 / 1e9, VALU_PEAK_GLOPS, "Glane-op/s"),
+            # all-pairs Hamming distance as an int8 matrix product: 256 multiply-adds = 512 operations per
+            # descriptor pair on the matrix cores (v_mfma_i32_32x32x32_i8)
+            "knn2": ("mfma", Bc * n_kp * n_kp * 512 / 1e12, MFMA_I8_PEAK_TOPS, "TOP/s") if args.matcher == "mfma" else
+                    # 8 XOR + 8 popcount-accumulate 32-bit lane operations per descriptor pair
+                    ("valu", Bc * n_kp * n_kp * 16 / 1e9, VALU_PEAK_GLOPS, "Glane-op/s"),
         }
         dominant = max(acc, key=acc.get)
         roof = {"kernel": dominant, "ms_per_launch": acc[dominant], "bound": None, "achieved": None,
@@ -250,7 +258,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
                                    ("orb8level" if levels else "fast1level"),
-                       "detector": args.detector, "pyramid_levels": levels or 1,
+                       "detector": args.detector, "matcher": args.matcher, "pyramid_levels": levels or 1,
                        "streams_per_gpu": S * NC, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
                        "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,

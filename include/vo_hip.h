@@ -113,6 +113,17 @@ int vo_detect(vo_ctx *ctx, const uint8_t *gray, int width, int height,
               int stride, int max_features, int fast_threshold, vo_kp *kps,
               uint8_t *desc, int *n_out);
 
+/* Which kernel computes the all-pairs Hamming distances of this context
+ * (vo_knn2_hamming, vo_match_features[_ex], the batched pipeline).  No
+ * counterpart in the reference (cv::BFMatcher picks its own loops): for
+ * measurements.  Both give identical results.
+ *   VO_MATCHER_MFMA      descriptor bits as int8 vectors on the matrix cores
+ *                        (default, the faster one);
+ *   VO_MATCHER_POPCOUNT  XOR + popcount on the vector ALU. */
+#define VO_MATCHER_MFMA 0
+#define VO_MATCHER_POPCOUNT 1
+int vo_set_matcher(vo_ctx *ctx, int kind);
+
 /* cv::BFMatcher(NORM_HAMMING, false).knnMatch(query, train, k = 2) on
  * 256-bit descriptors; equal distances keep the lower train index first.
  * reference src/feature_matcher.cpp:27-31 */

@@ -88,17 +88,29 @@ def test_knn2(ctx, oracle, vga_seq):
     assert np.array_equal(ctx.knn2(d0, d1), oracle.knn2(d0, d1))
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 1), (3, 2), (129, 513), (700, 3999), (4000, 4000)])
-def test_knn2_random_sizes_and_ties(ctx, oracle, nq, nt):
-    rng = np.random.default_rng(nq * 31 + nt)
-    # few distinct descriptors -> many exact distance ties; lowest index must win
-    pool = rng.integers(0, 256, (17, 32), dtype=np.uint8)
-    q = pool[rng.integers(0, 17, nq)]
-    t = pool[rng.integers(0, 17, nt)]
-    assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
-    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
-    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
-    assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+@pytest.mark.parametrize("matcher", ["mfma", "popcount"])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (5, 1), (3, 2), (33, 31), (129, 513), (700, 3999), (4000, 4000)])
+def test_knn2_random_sizes_and_ties(ctx, oracle, nq, nt, matcher):
+    """Both kernels (matrix cores / vector-ALU popcount) against the oracle, bit for bit."""
+    ctx.set_matcher(matcher)
+    try:
+        rng = np.random.default_rng(nq * 31 + nt)
+        # few distinct descriptors -> many exact distance ties; lowest index must win
+        pool = rng.integers(0, 256, (17, 32), dtype=np.uint8)
+        q = pool[rng.integers(0, 17, nq)]
+        t = pool[rng.integers(0, 17, nt)]
+        assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+        # extreme descriptors: all zeros / all ones (distances 0 and 256)
+        q = np.zeros((nq, 32), np.uint8)
+        q[::2] = 255
+        t = np.zeros((nt, 32), np.uint8)
+        t[1::3] = 255
+        assert np.array_equal(ctx.knn2(q, t), oracle.knn2(q, t))
+    finally:
+        ctx.set_matcher("mfma")
 
 
 def _pair_points(oracle, seq, nfeat=1000):

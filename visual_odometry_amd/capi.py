@@ -106,6 +106,7 @@ EXPORTS = {
     "vo_batch_get_matches": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vo_batch_get_inliers": (C.c_int, [_P, C.c_int, _P, _P]),
     "vo_batch_set_timing": (C.c_int, [_P, C.c_int]),
+    "vo_set_matcher": (C.c_int, [_P, C.c_int]),
     "vo_batch_stage_count": (C.c_int, []),
     "vo_batch_stage_name": (C.c_char_p, [C.c_int]),
     "vo_batch_get_timing": (C.c_int, [_P, _P]),
@@ -441,6 +442,11 @@ class Context:
         n = C.c_int(0)
         self._check(self._lib.vo_batch_get_inliers(self._h, frame, _ptr(out), C.addressof(n)))
         return out[:n.value].copy()
+
+    def set_matcher(self, kind: str):
+        """'mfma' (default): all-pairs Hamming distances on the matrix cores; 'popcount': XOR + popcount on the
+        vector ALU.  Identical results."""
+        self._check(self._lib.vo_set_matcher(self._h, {"mfma": 0, "popcount": 1}[kind]))
 
     def batch_set_timing(self, enable: bool):
         self._check(self._lib.vo_batch_set_timing(self._h, int(enable)))

@@ -200,9 +200,107 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
     }
 }
 
-void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp, const int *q_slot,
-                 const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, hipStream_t s)
+// ---- the same search on the vector ALU (selectable with vo_set_matcher(); the matrix-core kernel is the default)
+constexpr int KNP_THREADS = 128;
+constexpr int KNP_QPL = 2;                           // queries per lane
+constexpr int KNP_QPB = KNP_THREADS * KNP_QPL;       // queries per block
+constexpr int KNP_TILE = 128;                        // train descriptors per LDS tile
+
+// popcount(x) + acc in one instruction (v_bcnt_u32_b32); written out because the compiler otherwise
+// computes independent popcounts and adds them up with extra instructions
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc)
 {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+
+// Lane = query (two per lane, descriptors in registers), train tiles of 128
+// descriptors staged in LDS and read as wave-uniform broadcasts; per pair
+// eight XOR + eight chained accumulating popcounts, then the same key / min /
+// median-of-three update as above.  Same keys, same results.
+__global__ __launch_bounds__(KNP_THREADS) void k_knn2_popcount(const uint8_t *__restrict__ desc, size_t slot_stride,
+                                                      const int *__restrict__ nkp,
+                                                      const int *__restrict__ q_slot,
+                                                      const int *__restrict__ t_slot, int kp_stride,
+                                                      uint2 *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) uint4 s_tile[KNP_TILE * 2];
+
+    const int pair = blockIdx.z, split = blockIdx.y;
+    // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
+    const int qs = __builtin_amdgcn_readfirstlane(q_slot[pair]), ts = __builtin_amdgcn_readfirstlane(t_slot[pair]);
+    const int nq = __builtin_amdgcn_readfirstlane(nkp[qs]), nt = __builtin_amdgcn_readfirstlane(nkp[ts]);
+    const int qbase = blockIdx.x * KNP_QPB;
+    if (qbase >= nq) return;
+
+    const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
+    const uint4 *td = reinterpret_cast<const uint4 *>(desc + ts * slot_stride);
+
+    uint4 qa[KNP_QPL], qb[KNP_QPL];
+    uint32_t k0[KNP_QPL], k1[KNP_QPL];
+#pragma unroll
+    for (int i = 0; i < KNP_QPL; i++) {
+        const int q = min(qbase + i * KNP_THREADS + (int)threadIdx.x, nq - 1);
+        qa[i] = qd[2 * q];
+        qb[i] = qd[2 * q + 1];
+        k0[i] = k1[i] = 0xffffffffu;
+    }
+
+    // this block's share of the train set: an even cut of the descriptors
+    const int j_lo = (int)(((long long)nt * split) / kKnnSplits);
+    const int j_hi = (int)(((long long)nt * (split + 1)) / kKnnSplits);
+
+    for (int j0 = j_lo; j0 < j_hi; j0 += KNP_TILE) {
+        const int jn = min(KNP_TILE, j_hi - j0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < jn * 2; i += KNP_THREADS) s_tile[i] = td[2 * j0 + i];
+        __syncthreads();
+        auto one = [&](int j) {
+            const uint4 ta = s_tile[2 * j], tb = s_tile[2 * j + 1];  // wave-uniform: LDS broadcast
+            const uint32_t jj = (uint32_t)(j0 + j);
+#pragma unroll
+            for (int i = 0; i < KNP_QPL; i++) {
+                // eight XOR + eight accumulating popcounts (the accumulation is chained on purpose)
+                uint32_t d = popc_acc(qa[i].x ^ ta.x, 0u);
+                d = popc_acc(qa[i].y ^ ta.y, d);
+                d = popc_acc(qa[i].z ^ ta.z, d);
+                d = popc_acc(qa[i].w ^ ta.w, d);
+                d = popc_acc(qb[i].x ^ tb.x, d);
+                d = popc_acc(qb[i].y ^ tb.y, d);
+                d = popc_acc(qb[i].z ^ tb.z, d);
+                d = popc_acc(qb[i].w ^ tb.w, d);
+                const uint32_t key = (d << 16) | jj;
+                // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
+                k1[i] = umed3(k0[i], k1[i], key);
+                k0[i] = min(k0[i], key);
+            }
+        };
+        int j = 0;
+        for (; j + 4 <= jn; j += 4) {
+            one(j); one(j + 1); one(j + 2); one(j + 3);
+        }
+        for (; j < jn; j++) one(j);
+    }
+
+#pragma unroll
+    for (int i = 0; i < KNP_QPL; i++) {
+        const int q = qbase + i * KNP_THREADS + (int)threadIdx.x;
+        if (q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(k0[i], k1[i]);
+    }
+}
+
+void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp, const int *q_slot,
+                 const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, bool popcount,
+                 hipStream_t s)
+{
+    if (popcount) {
+        dim3 grid((max_n + KNP_QPB - 1) / KNP_QPB, kKnnSplits, pairs);
+        hipLaunchKernelGGL(k_knn2_popcount, grid, dim3(KNP_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot,
+                           t_slot, kp_stride, partial);
+        return;
+    }
     dim3 grid((max_n + KNN_QPB - 1) / KNN_QPB, kKnnSplits, pairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(KNN_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot, t_slot,
                        kp_stride, partial);

@@ -450,6 +450,14 @@ int vo_orb_get_level(vo_ctx *c, int frame, int level, int blurred, uint8_t *dst,
     return VO_OK;
 }
 
+int vo_set_matcher(vo_ctx *c, int kind)
+{
+    if (!c) return VO_ERR_ARG;
+    if (kind != VO_MATCHER_MFMA && kind != VO_MATCHER_POPCOUNT) return fail(c, VO_ERR_ARG, "vo_set_matcher: kind %d", kind);
+    c->matcher_popcount = kind == VO_MATCHER_POPCOUNT;
+    return VO_OK;
+}
+
 int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *train, int nt, vo_knn2 *out)
 {
     if (!c) return VO_ERR_ARG;
@@ -463,7 +471,7 @@ int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *trai
     if ((rc = upload_features(c, c->op_slot1, nullptr, train, nt))) return rc;
     if ((rc = set_single_pair(c))) return rc;
     launch_knn2(c->d_desc, (size_t)c->kp_stride * 32, c->d_nkp, c->d_qslot, c->d_tslot, c->kp_stride,
-                c->d_partial, c->kp_stride, 1, c->stream);
+                c->d_partial, c->kp_stride, 1, c->matcher_popcount, c->stream);
     launch_match_finalize(c->d_partial, c->d_kps, c->kp_stride, c->d_nkp, c->d_qslot, c->d_tslot, 0.7f, nullptr,
                           c->d_knn, c->d_good, c->d_ngood, 1, c->stream);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_knn, sizeof(vo_knn2) * nq, hipMemcpyDefault, c->stream));
@@ -746,10 +754,10 @@ void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacPara
 {
     mark(5);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
-                pairs, stream);
+                pairs, matcher_popcount, stream);
     if (cross_check)  // the same pairs with the roles of query and train swapped
         launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_tslot, d_qslot, kp_stride, d_partial_rev, kp_stride,
-                    pairs, stream);
+                    pairs, matcher_popcount, stream);
     mark(6);
     launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio,
                           cross_check ? d_partial_rev : nullptr, d_knn, d_good, d_ngood, pairs, stream);

@@ -70,6 +70,7 @@ struct vo_ctx {
     int ensure_stereo();
     bool depth_planes_nan = false;  // d_depth holds nothing but NaN (stereo batches keep it that way)
     bool marks_on = true;           // timing events are recorded by mark()
+    bool matcher_popcount = false;  // kNN-2 on the vector ALU instead of the matrix cores (vo_set_matcher)
     vo_stereo_cfg stereo_cfg{};
     bool last_batch_stereo = false;
 

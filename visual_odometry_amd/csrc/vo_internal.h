@@ -116,9 +116,10 @@ void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride,
 
 // Hamming kNN-2. For pair p the query set is (q_desc + q_slot[p]*slot_stride,
 // n[q_slot[p]]) and the train set likewise. partial: [pair][split][kp_stride] uint2.
+// popcount: the XOR / popcount kernel on the vector ALU instead of the matrix-core kernel (same results).
 void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp,
                  const int *q_slot, const int *t_slot, int kp_stride,
-                 uint2 *partial, int max_n, int pairs, hipStream_t s);
+                 uint2 *partial, int max_n, int pairs, bool popcount, hipStream_t s);
 
 // ImageProcessor stages (reference src/image_processor.cpp:41-79), one plane.
 void launch_hist256(const uint8_t *img, int w, int h, int pitch, uint32_t *hist, hipStream_t s);
