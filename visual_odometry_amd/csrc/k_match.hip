@@ -46,14 +46,14 @@ __device__ __forceinline__ uint32_t nibble_bytes(uint32_t x, int i)
 // (distance, then lower train index), the order in which
 // cv::BFMatcher::knnMatch reports equal distances (reference
 // src/feature_matcher.cpp:27-31).  Integer arithmetic throughout: bit-exact.
-__global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
+__global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
                                                       const int *__restrict__ nkp,
                                                       const int *__restrict__ q_slot,
                                                       const int *__restrict__ t_slot, int kp_stride,
                                                       uint2 *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][KNN_TILE * KNN_ROW];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[2][KNN_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[3][KNN_TILE];  // train words of tiles t-1, t, t+1
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         const int j = j_lo + t * KNN_TILE + sr;
         return td[(size_t)min(j, nt - 1) * 8 + sc] & (j < j_hi ? 0xffffffffu : 0u);  // rows past the share: all zero
     };
-    auto stage = [&](int buf, int t, uint32_t x) {
+    auto stage = [&](int buf, int wbuf, int t, uint32_t x) {
         uint4 a, b;
         a.x = nibble_bytes(x, 0); a.y = nibble_bytes(x, 1); a.z = nibble_bytes(x, 2); a.w = nibble_bytes(x, 3);
         b.x = nibble_bytes(x, 4); b.y = nibble_bytes(x, 5); b.z = nibble_bytes(x, 6); b.w = nibble_bytes(x, 7);
@@ -117,26 +117,50 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
         p += __shfl_xor(p, 4);
         const int j = j_lo + t * KNN_TILE + sr;
         // rows past the share have all-zero bytes (accumulator 0) and the largest key
-        if (sc == 0) s_c[buf][sr] = j < j_hi ? ((p + 512u) << 16) | (uint32_t)j : 0xffffffffu;
+        if (sc == 0) s_c[wbuf][sr] = j < j_hi ? ((p + 512u) << 16) | (uint32_t)j : 0xffffffffu;
     };
 
     // One step = one tile.  The two accumulation chains of a tile (query sets 0 and 1) are issued one after
     // the other; the top-2 updates of a finished chain are placed in the issue gaps of the next chain (two
     // accumulator registers = six vector instructions per MFMA), so set 1 of tile t-1 is consumed under chain 0
-    // of tile t and set 0 of tile t under chain 1 of tile t.  cwc / cwp: the train words of this / the previous
-    // tile (register sets alternate between steps).
+    // of tile t and set 0 of tile t under chain 1 of tile t.  The train words are fetched from LDS four at a
+    // time, one fetch ahead (s_c keeps three tiles: t-1 is still read while t+1 is written).
     v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-    auto update2 = [&](int s, const v16i &acc, const uint32_t (&cw)[16], int r) {
+    auto update = [&](int s, uint32_t a, uint32_t w) {
+        const uint32_t key = (a << 17) + w;
+        // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
+        k1[s] = umed3(k0[s], k1[s], key);
+        k0[s] = min(k0[s], key);
+    };
+    // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
+    auto words = [&](int wb, int g) { return *reinterpret_cast<const uint4 *>(&s_c[wb][8 * g + 4 * half]); };
+    // the chain of query set s over the tile in A, with the updates of set 1 - s (accumulator `done`, words wb)
+    auto chain = [&](int s, v16i &acc, const v4i (&A)[8], const v16i &done, int wb) {
+        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint4 w = words(wb, 0), wn = w;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t key = ((uint32_t)acc[r + i] << 17) + cw[r + i];
-            // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
-            k1[s] = umed3(k0[s], k1[s], key);
-            k0[s] = min(k0[s], key);
+        for (int ks = 0; ks < 8; ks++) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], ks == 0 ? zero : acc, 0, 0, 0);
+            if ((ks & 1) == 0) {
+                if (ks < 6) wn = words(wb, ks / 2 + 1);
+                update(1 - s, (uint32_t)done[2 * ks], w.x);
+                update(1 - s, (uint32_t)done[2 * ks + 1], w.y);
+            } else {
+                update(1 - s, (uint32_t)done[2 * ks], w.z);
+                update(1 - s, (uint32_t)done[2 * ks + 1], w.w);
+                w = wn;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto step = [&](int t, uint32_t (&cwc)[16], const uint32_t (&cwp)[16]) {
+
+    if (tid < KNN_TILE) s_c[2][tid] = 0xffffffffu;  // "tile -1": with acc1 = 0, keys that change nothing
+    if (ntiles > 0) stage(0, 0, 0, load_packed(0));
+    __syncthreads();
+    int wcur = 0;  // t % 3
+    for (int t = 0; t < ntiles; t++) {
         const int buf = t & 1;
+        const int wprev = wcur == 0 ? 2 : wcur - 1, wnext = wcur == 2 ? 0 : wcur + 1;
         const bool more = t + 1 < ntiles;  // block-uniform
         uint32_t next = 0;
         if (more) next = load_packed(t + 1);
@@ -144,47 +168,24 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn2(const uint8_t *__restrict_
 #pragma unroll
         for (int ks = 0; ks < 8; ks++)
             A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
-        // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
+        __builtin_amdgcn_sched_barrier(0);
+        chain(0, acc0, A, acc1, wprev);
+        chain(1, acc1, A, acc0, wcur);
+        if (more) stage(buf ^ 1, wnext, t + 1, next);
+        __syncthreads();
+        wcur = wnext;
+    }
+    // set 1 of the last tile
+    if (ntiles > 0) {
+        const int wlast = wcur == 0 ? 2 : wcur - 1;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&s_c[buf][8 * g + 4 * half]);
-            cwc[4 * g] = v.x; cwc[4 * g + 1] = v.y; cwc[4 * g + 2] = v.z; cwc[4 * g + 3] = v.w;
+            const uint4 w = words(wlast, g);
+            update(1, (uint32_t)acc1[4 * g], w.x);
+            update(1, (uint32_t)acc1[4 * g + 1], w.y);
+            update(1, (uint32_t)acc1[4 * g + 2], w.z);
+            update(1, (uint32_t)acc1[4 * g + 3], w.w);
         }
-        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[0][ks], ks == 0 ? zero : acc0, 0, 0, 0);
-            update2(1, acc1, cwp, 2 * ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[1][ks], ks == 0 ? zero : acc1, 0, 0, 0);
-            update2(0, acc0, cwc, 2 * ks);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) stage(buf ^ 1, t + 1, next);
-        __syncthreads();
-    };
-
-    if (ntiles > 0) stage(0, 0, load_packed(0));
-    __syncthreads();
-    uint32_t cwa[16], cwb[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) cwa[r] = cwb[r] = 0xffffffffu;  // with acc1 = 0: keys that change nothing
-    for (int t = 0; t < ntiles; t += 2) {
-        step(t, cwa, cwb);
-        if (t + 1 < ntiles) step(t + 1, cwb, cwa);
-        else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) cwb[r] = cwa[r];  // the last tile's words, for the tail below
-        }
-    }
-    // set 1 of the last tile (cwb holds its words after an even or an odd number of tiles)
-    if (ntiles > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) update2(1, acc1, cwb, r);
     }
 
 #pragma unroll
