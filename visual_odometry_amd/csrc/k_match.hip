@@ -23,37 +23,49 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-// bits 4i .. 4i+3 of x as four bytes holding 0 or 1 (bit 4i+j in byte j): the multiplier puts bit j at position 8j
-__device__ __forceinline__ uint32_t nibble_bytes(uint32_t x, int i)
+// Key scale: a key is kKeyScale * (distance part) + train index, so the scale must exceed every train index
+// (vo_cfg.max_features <= 6144) -- and it is half the magnitude of the byte product the MFMA accumulates per
+// common bit, (-128) * 96 = -2 * 6144.
+constexpr uint32_t kKeyScale = 6144;
+static_assert(kKeyScale * 2 == 128 * 96, "train byte -128, query byte 96");
+
+// bits 4i .. 4i+3 of x spread to bit `pos` of four bytes (bit 4i+j in byte j): the multiplier puts bit j at 8j
+template <int pos>
+__device__ __forceinline__ uint32_t nibble_spread(uint32_t x, int i)
 {
-    return __umul24((x >> (4 * i)) & 15u, 0x204081u) & 0x01010101u;
+    const int sh = 4 * i - pos;  // the nibble ends up at bits pos .. pos+3 before the multiplication
+    const uint32_t n = (sh >= 0 ? x >> (sh & 31) : x << ((-sh) & 31)) & (15u << pos);
+    return __umul24(n, 0x204081u) & (0x01010101u << pos);  // (15 << 7) * 0x204081 < 2^32
 }
 
 // Brute-force Hamming kNN-2 on the matrix cores.  For descriptors as 0/1
 // vectors the distance is |q| + |t| - 2 <q, t>, so all pairs of a 32-train x
 // 32-query tile come out of eight v_mfma_i32_32x32x32_i8 (K = 256 bits as
-// bytes).  A block holds 256 queries in registers for its whole life (the MFMA
-// B operand, bytes 0 / -1, so the products accumulate -<q, t>) and streams the
-// trains of its share 32 at a time: the packed descriptors are expanded to
-// bytes 0 / 1 in LDS (double-buffered; the next tile's words are in flight
-// during the MFMAs) together with a word (|t| + 512) << 16 | train index per
-// train.  With the query on the lane (MFMA column) and 16 trains in a lane's
-// accumulator registers, the running two smallest keys of a query cost three
-// vector instructions per pair:
-//   key = (acc << 17) + word = (|t| + 512 - 2 <q, t>) << 16 | index,
-//   k1 = med3(k0, k1, key), k0 = min(k0, key);
-// |q| - 512 is added to the distance field at the end.  Keys order by
-// (distance, then lower train index), the order in which
+// bytes).  The products are scaled so that the accumulator IS the sort key:
+// train bits become bytes 0 / -128, query bits 0 / 96, and the accumulator of
+// train row t starts at the word S (|t| + 512) + index(t), S = 6144, so that
+// after the eight MFMAs it holds
+//   S (|t| + 512 - 2 <q, t>) + index(t)
+// -- ordered by (distance, then lower train index), the order in which
 // cv::BFMatcher::knnMatch reports equal distances (reference
-// src/feature_matcher.cpp:27-31).  Integer arithmetic throughout: bit-exact.
-__global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride,
-                                                      const int *__restrict__ nkp,
-                                                      const int *__restrict__ q_slot,
-                                                      const int *__restrict__ t_slot, int kp_stride,
-                                                      uint2 *__restrict__ partial)
+// src/feature_matcher.cpp:27-31).  With the query on the lane (MFMA column)
+// and 16 trains in a lane's accumulator registers, the running two smallest
+// keys of a query cost two vector instructions per pair:
+//   k1 = med3(k0, k1, key), k0 = min(k0, key);
+// distance and index are taken apart once per query at the end (|q| - 512 is
+// added to the distance there).  A block holds 256 queries in registers for
+// its whole life (the MFMA B operands) and streams the trains of its share 32
+// at a time: the packed descriptors are expanded to bytes in LDS
+// (double-buffered; the next tile's packed words are in flight during the
+// MFMAs) together with the word of each train.  Integer arithmetic
+// throughout: bit-exact.
+__global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__restrict__ nkp,
+            const int *__restrict__ q_slot, const int *__restrict__ t_slot, int kp_stride,
+            uint2 *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[2][KNN_TILE * KNN_ROW];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[3][KNN_TILE];  // train words of tiles t-1, t, t+1
+    __shared__ __attribute__((aligned(16))) uint32_t s_c[2][KNN_TILE];
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -67,26 +79,25 @@ __global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
     const uint32_t *td = reinterpret_cast<const uint32_t *>(desc + ts * slot_stride);
 
-    // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes 0 / -1
+    // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes 0 / 96
     v4i B[2][8];
-    uint32_t fix[2], k0[2], k1[2];
+    uint32_t pq[2], k0[2], k1[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int q = min(qbase + wave * KNN_QPW + 32 * s + col, nq - 1);
         const uint4 lo = qd[2 * q], hi = qd[2 * q + 1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint32_t pq = 0;
+        pq[s] = 0;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            pq += __popc(w[ks]);
+            pq[s] += __popc(w[ks]);
             const uint32_t bits = (w[ks] >> (16 * half)) & 0xffffu;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t m = nibble_bytes(bits, j);
-                B[s][ks][j] = (int)((m << 8) - m);  // 1 -> 0xff in every byte
+                const uint32_t m = nibble_spread<5>(bits, j);  // 0 / 32
+                B[s][ks][j] = (int)(m + 2 * m);                // 0 / 96
             }
         }
-        fix[s] = (pq - 512u) << 16;
         k0[s] = k1[s] = 0xffffffffu;
     }
 
@@ -101,103 +112,100 @@ __global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         const int j = j_lo + t * KNN_TILE + sr;
         return td[(size_t)min(j, nt - 1) * 8 + sc] & (j < j_hi ? 0xffffffffu : 0u);  // rows past the share: all zero
     };
-    auto stage = [&](int buf, int wbuf, int t, uint32_t x) {
-        uint4 a, b;
-        a.x = nibble_bytes(x, 0); a.y = nibble_bytes(x, 1); a.z = nibble_bytes(x, 2); a.w = nibble_bytes(x, 3);
-        b.x = nibble_bytes(x, 4); b.y = nibble_bytes(x, 5); b.z = nibble_bytes(x, 6); b.w = nibble_bytes(x, 7);
+    auto stage = [&](int buf, int t, uint32_t x) {
+        uint4 a, b;  // bytes 0 / 0x80 (-128)
+        a.x = nibble_spread<7>(x, 0); a.y = nibble_spread<7>(x, 1); a.z = nibble_spread<7>(x, 2); a.w = nibble_spread<7>(x, 3);
+        b.x = nibble_spread<7>(x, 4); b.y = nibble_spread<7>(x, 5); b.z = nibble_spread<7>(x, 6); b.w = nibble_spread<7>(x, 7);
         // the two 16-byte halves of words 4 .. 7 are swapped, so that the eight lanes of a train write (and the
         // MFMA operand reads below fetch) distinct banks
         uint8_t *row = &s_a[buf][sr * KNN_ROW + 32 * sc];
         const int sw = (sc >> 2) * 16;
         *reinterpret_cast<uint4 *>(row + sw) = a;
         *reinterpret_cast<uint4 *>(row + (16 - sw)) = b;
-        uint32_t p = __popc(x);
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        p += __shfl_xor(p, 4);
+        // |t| over the train's eight lanes: cross-lane adds inside the vector ALU (quad permutes, then the
+        // mirrored half row pairs the two quads)
+        int p = (int)__popc(x);
+        p += __builtin_amdgcn_mov_dpp(p, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        p += __builtin_amdgcn_mov_dpp(p, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        p += __builtin_amdgcn_mov_dpp(p, 0x141, 0xf, 0xf, true);  // row_half_mirror
         const int j = j_lo + t * KNN_TILE + sr;
-        // rows past the share have all-zero bytes (accumulator 0) and the largest key
-        if (sc == 0) s_c[wbuf][sr] = j < j_hi ? ((p + 512u) << 16) | (uint32_t)j : 0xffffffffu;
+        // rows past the share have all-zero bytes (the accumulator keeps its start) and the largest positive start
+        if (sc == 0) s_c[buf][sr] = j < j_hi ? kKeyScale * ((uint32_t)p + 512u) + (uint32_t)j : 0x7fffffffu;
     };
 
     // One step = one tile.  The two accumulation chains of a tile (query sets 0 and 1) are issued one after
     // the other; the top-2 updates of a finished chain are placed in the issue gaps of the next chain (two
-    // accumulator registers = six vector instructions per MFMA), so set 1 of tile t-1 is consumed under chain 0
-    // of tile t and set 0 of tile t under chain 1 of tile t.  The train words are fetched from LDS four at a
-    // time, one fetch ahead (s_c keeps three tiles: t-1 is still read while t+1 is written).
-    v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
-    auto update = [&](int s, uint32_t a, uint32_t w) {
-        const uint32_t key = (a << 17) + w;
+    // accumulator registers = four vector instructions per MFMA), so set 1 of tile t-1 is consumed under chain 0
+    // of tile t and set 0 of tile t under chain 1 of tile t.
+    auto update = [&](int s, int key) {
         // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
-        k1[s] = umed3(k0[s], k1[s], key);
-        k0[s] = min(k0[s], key);
+        k1[s] = umed3(k0[s], k1[s], (uint32_t)key);
+        k0[s] = min(k0[s], (uint32_t)key);
     };
-    // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
-    auto words = [&](int wb, int g) { return *reinterpret_cast<const uint4 *>(&s_c[wb][8 * g + 4 * half]); };
-    // the chain of query set s over the tile in A, with the updates of set 1 - s (accumulator `done`, words wb)
-    auto chain = [&](int s, v16i &acc, const v4i (&A)[8], const v16i &done, int wb) {
-        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        uint4 w = words(wb, 0), wn = w;
+    // the start values of a tile's accumulators: register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half
+    auto words = [&](int buf) {
+        v16i c;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_c[buf][8 * g + 4 * half]);
+            c[4 * g] = (int)v.x; c[4 * g + 1] = (int)v.y; c[4 * g + 2] = (int)v.z; c[4 * g + 3] = (int)v.w;
+        }
+        return c;
+    };
+    // the chain of query set s over the tile in A, with the updates of set 1 - s (accumulator `done`)
+    auto chain = [&](int s, v16i &acc, const v16i &start, const v4i (&A)[8], const v16i &done) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], ks == 0 ? zero : acc, 0, 0, 0);
-            if ((ks & 1) == 0) {
-                if (ks < 6) wn = words(wb, ks / 2 + 1);
-                update(1 - s, (uint32_t)done[2 * ks], w.x);
-                update(1 - s, (uint32_t)done[2 * ks + 1], w.y);
-            } else {
-                update(1 - s, (uint32_t)done[2 * ks], w.z);
-                update(1 - s, (uint32_t)done[2 * ks + 1], w.w);
-                w = wn;
-            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], ks == 0 ? start : acc, 0, 0, 0);
+            update(1 - s, done[2 * ks]);
+            update(1 - s, done[2 * ks + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    if (tid < KNN_TILE) s_c[2][tid] = 0xffffffffu;  // "tile -1": with acc1 = 0, keys that change nothing
-    if (ntiles > 0) stage(0, 0, 0, load_packed(0));
+    v16i acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = -1;  // "tile -1": keys that change nothing
+    // tile t+1 is expanded at the start of step t (from packed words loaded during step t-1), while the operand
+    // reads of tile t are in flight
+    if (ntiles > 0) stage(0, 0, load_packed(0));
+    uint32_t next = ntiles > 1 ? load_packed(1) : 0u;
     __syncthreads();
-    int wcur = 0;  // t % 3
     for (int t = 0; t < ntiles; t++) {
         const int buf = t & 1;
-        const int wprev = wcur == 0 ? 2 : wcur - 1, wnext = wcur == 2 ? 0 : wcur + 1;
-        const bool more = t + 1 < ntiles;  // block-uniform
-        uint32_t next = 0;
-        if (more) next = load_packed(t + 1);
         v4i A[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ks++)
             A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
+        const v16i start = words(buf);
+        if (t + 1 < ntiles) stage(buf ^ 1, t + 1, next);  // block-uniform
+        if (t + 2 < ntiles) next = load_packed(t + 2);
         __builtin_amdgcn_sched_barrier(0);
-        chain(0, acc0, A, acc1, wprev);
-        chain(1, acc1, A, acc0, wcur);
-        if (more) stage(buf ^ 1, wnext, t + 1, next);
+        chain(0, acc0, start, A, acc1);
+        chain(1, acc1, start, A, acc0);
         __syncthreads();
-        wcur = wnext;
     }
     // set 1 of the last tile
     if (ntiles > 0) {
-        const int wlast = wcur == 0 ? 2 : wcur - 1;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint4 w = words(wlast, g);
-            update(1, (uint32_t)acc1[4 * g], w.x);
-            update(1, (uint32_t)acc1[4 * g + 1], w.y);
-            update(1, (uint32_t)acc1[4 * g + 2], w.z);
-            update(1, (uint32_t)acc1[4 * g + 3], w.w);
-        }
+        for (int r = 0; r < 16; r++) update(1, acc1[r]);
     }
 
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         // the other half of the wave holds the other 16 rows of every tile for the same query
         const uint32_t o0 = __shfl_xor(k0[s], 32), o1 = __shfl_xor(k1[s], 32);
-        uint32_t n0 = min(k0[s], o0);
-        uint32_t n1 = min(max(k0[s], o0), min(k1[s], o1));
-        if (n0 != 0xffffffffu) n0 += fix[s];
-        if (n1 != 0xffffffffu) n1 += fix[s];
+        const uint32_t n0 = min(k0[s], o0);
+        const uint32_t n1 = min(max(k0[s], o0), min(k1[s], o1));
+        // key -> (distance << 16) | train index; keys of rows past the share (and the initial ones) mean "none"
+        auto finish = [&](uint32_t k) {
+            if (k >= 0x7fffffffu) return 0xffffffffu;
+            const uint32_t dpart = k / kKeyScale, idx = k - dpart * kKeyScale;
+            return ((dpart + pq[s] - 512u) << 16) | idx;
+        };
         const int q = qbase + wave * KNN_QPW + 32 * s + col;
-        if (half == 0 && q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(n0, n1);
+        if (half == 0 && q < nq)
+            partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(finish(n0), finish(n1));
     }
 }
 
