@@ -113,6 +113,30 @@ def test_knn2_random_sizes_and_ties(ctx, oracle, nq, nt, matcher):
         ctx.set_matcher("mfma")
 
 
+@pytest.mark.parametrize("matcher", ["mfma", "popcount"])
+def test_knn2_at_the_feature_limit(oracle, matcher):
+    """6144 x 6144 descriptors, the largest set a context accepts (the matrix-core kernel's keys hold the train
+    index below a scale of 6144), with clustered descriptors so that ties reach the highest indices."""
+    from visual_odometry_amd import capi
+    big = capi.Context(0, 640, 480, 6144, 2)
+    try:
+        big.set_matcher(matcher)
+        rng = np.random.default_rng(6144)
+        pool = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+        q = pool[rng.integers(0, 40, 6144)].copy()
+        t = pool[rng.integers(0, 40, 6144)].copy()
+        t[-1] = q[0]
+        t[-2] = q[0]  # the nearest two of query 0 may be the last two trains
+        flips = rng.integers(0, 256, (6144, 32), dtype=np.uint8) & rng.integers(0, 256, (6144, 32), dtype=np.uint8) & 3
+        t[: 6000] ^= flips[: 6000]
+        ref = oracle.knn2(q, t)
+        got = big.knn2(q, t)
+        assert np.array_equal(got, ref)
+        assert ref["idx0"].max() >= 6000
+    finally:
+        big.close()
+
+
 def _pair_points(oracle, seq, nfeat=1000):
     g0, g1 = (oracle.gray(f) for f in seq["frames"][:2])
     k0, d0 = oracle.detect(g0, nfeat, 20)
