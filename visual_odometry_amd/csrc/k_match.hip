@@ -23,11 +23,13 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-// Key scale: a key is kKeyScale * (distance part) + train index, so the scale must exceed every train index
-// (vo_cfg.max_features <= 6144) -- and it is half the magnitude of the byte product the MFMA accumulates per
-// common bit, (-128) * 96 = -2 * 6144.
-constexpr uint32_t kKeyScale = 6144;
-static_assert(kKeyScale * 2 == 128 * 96, "train byte -128, query byte 96");
+// Key scale: a key is kKeyScale * distance + train index, so the scale must exceed every train index
+// (vo_cfg.max_features <= 6144) -- and it is twice the magnitude of the byte product of the MFMA operands,
+// 64 * 48 = 6144 / 2.
+constexpr int kKeyScale = 6144;
+constexpr int kKeyBias = 256 * (kKeyScale / 2);  // what the products of 256 equal bits sum to
+static_assert(kKeyScale == 2 * 64 * 48, "train bytes +-64, query bytes -+48");
+constexpr uint32_t kKeyNone = 0x7e000000u;       // keys at or above: no train
 
 // bits 4i .. 4i+3 of x spread to bit `pos` of four bytes (bit 4i+j in byte j): the multiplier puts bit j at 8j
 template <int pos>
@@ -38,34 +40,31 @@ __device__ __forceinline__ uint32_t nibble_spread(uint32_t x, int i)
     return __umul24(n, 0x204081u) & (0x01010101u << pos);  // (15 << 7) * 0x204081 < 2^32
 }
 
-// Brute-force Hamming kNN-2 on the matrix cores.  For descriptors as 0/1
-// vectors the distance is |q| + |t| - 2 <q, t>, so all pairs of a 32-train x
-// 32-query tile come out of eight v_mfma_i32_32x32x32_i8 (K = 256 bits as
-// bytes).  The products are scaled so that the accumulator IS the sort key:
-// train bits become bytes 0 / -128, query bits 0 / 96, and the accumulator of
-// train row t starts at the word S (|t| + 512) + index(t), S = 6144, so that
-// after the eight MFMAs it holds
-//   S (|t| + 512 - 2 <q, t>) + index(t)
+// Brute-force Hamming kNN-2 on the matrix cores.  With descriptor bits as
+// +-1 the inner product of two descriptors is 256 - 2 d (d = Hamming
+// distance), so all pairs of a 32-train x 32-query tile come out of eight
+// v_mfma_i32_32x32x32_i8 (K = 256 bits as bytes).  The byte values are chosen
+// so that the accumulator IS the sort key: train bits become +64 / -64, query
+// bits -48 / +48 (the products sum to 6144 d - 786432), and the accumulator
+// of train t starts at 786432 + index(t): after the eight MFMAs it holds
+//   6144 d + index(t)
 // -- ordered by (distance, then lower train index), the order in which
 // cv::BFMatcher::knnMatch reports equal distances (reference
 // src/feature_matcher.cpp:27-31).  With the query on the lane (MFMA column)
 // and 16 trains in a lane's accumulator registers, the running two smallest
 // keys of a query cost two vector instructions per pair:
 //   k1 = med3(k0, k1, key), k0 = min(k0, key);
-// distance and index are taken apart once per query at the end (|q| - 512 is
-// added to the distance there).  A block holds 256 queries in registers for
-// its whole life (the MFMA B operands) and streams the trains of its share 32
-// at a time: the packed descriptors are expanded to bytes in LDS
-// (double-buffered; the next tile's packed words are in flight during the
-// MFMAs) together with the word of each train.  Integer arithmetic
-// throughout: bit-exact.
+// distance and index are taken apart once per query at the end.  A block
+// holds 256 queries in registers for its whole life (the MFMA B operands) and
+// streams the trains of its share 32 at a time: the packed descriptors are
+// expanded to bytes in LDS (double-buffered; the next tile's packed words are
+// loaded a step ahead).  Integer arithmetic throughout: bit-exact.
 __global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__restrict__ nkp,
             const int *__restrict__ q_slot, const int *__restrict__ t_slot, int kp_stride,
             uint2 *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_a[2][KNN_TILE * KNN_ROW];
-    __shared__ __attribute__((aligned(16))) uint32_t s_c[2][KNN_TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[3][KNN_TILE * KNN_ROW];  // tiles t, t+1, t+2
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -79,23 +78,21 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
     const uint32_t *td = reinterpret_cast<const uint32_t *>(desc + ts * slot_stride);
 
-    // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes 0 / 96
+    // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes -48 (bit set) / +48
     v4i B[2][8];
-    uint32_t pq[2], k0[2], k1[2];
+    uint32_t k0[2], k1[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int q = min(qbase + wave * KNN_QPW + 32 * s + col, nq - 1);
         const uint4 lo = qd[2 * q], hi = qd[2 * q + 1];
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        pq[s] = 0;
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
-            pq[s] += __popc(w[ks]);
             const uint32_t bits = (w[ks] >> (16 * half)) & 0xffffu;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t m = nibble_spread<5>(bits, j);  // 0 / 32
-                B[s][ks][j] = (int)(m + 2 * m);                // 0 / 96
+                const uint32_t m = nibble_spread<5>(bits, j);          // 0x20 per set bit
+                B[s][ks][j] = (int)(0x30303030u ^ ((m << 3) - m));     // 0x30 ^ 0xe0 = 0xd0 = -48
             }
         }
         k0[s] = k1[s] = 0xffffffffu;
@@ -109,28 +106,18 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     // staging role of this thread: word sc of train sr of the tile
     const int sr = tid >> 3, sc = tid & 7;
     auto load_packed = [&](int t) -> uint32_t {
-        const int j = j_lo + t * KNN_TILE + sr;
-        return td[(size_t)min(j, nt - 1) * 8 + sc] & (j < j_hi ? 0xffffffffu : 0u);  // rows past the share: all zero
+        return td[(size_t)min(j_lo + t * KNN_TILE + sr, nt - 1) * 8 + sc];  // rows past the share: any train
     };
-    auto stage = [&](int buf, int t, uint32_t x) {
-        uint4 a, b;  // bytes 0 / 0x80 (-128)
-        a.x = nibble_spread<7>(x, 0); a.y = nibble_spread<7>(x, 1); a.z = nibble_spread<7>(x, 2); a.w = nibble_spread<7>(x, 3);
-        b.x = nibble_spread<7>(x, 4); b.y = nibble_spread<7>(x, 5); b.z = nibble_spread<7>(x, 6); b.w = nibble_spread<7>(x, 7);
+    auto stage = [&](int buf, uint32_t x) {
+        uint32_t e[8];  // bytes +64 (bit set) / -64
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = nibble_spread<7>(x, i) ^ 0xc0c0c0c0u;
         // the two 16-byte halves of words 4 .. 7 are swapped, so that the eight lanes of a train write (and the
         // MFMA operand reads below fetch) distinct banks
         uint8_t *row = &s_a[buf][sr * KNN_ROW + 32 * sc];
         const int sw = (sc >> 2) * 16;
-        *reinterpret_cast<uint4 *>(row + sw) = a;
-        *reinterpret_cast<uint4 *>(row + (16 - sw)) = b;
-        // |t| over the train's eight lanes: cross-lane adds inside the vector ALU (quad permutes, then the
-        // mirrored half row pairs the two quads)
-        int p = (int)__popc(x);
-        p += __builtin_amdgcn_mov_dpp(p, 0xb1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-        p += __builtin_amdgcn_mov_dpp(p, 0x4e, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-        p += __builtin_amdgcn_mov_dpp(p, 0x141, 0xf, 0xf, true);  // row_half_mirror
-        const int j = j_lo + t * KNN_TILE + sr;
-        // rows past the share have all-zero bytes (the accumulator keeps its start) and the largest positive start
-        if (sc == 0) s_c[buf][sr] = j < j_hi ? kKeyScale * ((uint32_t)p + 512u) + (uint32_t)j : 0x7fffffffu;
+        *reinterpret_cast<uint4 *>(row + sw) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4 *>(row + (16 - sw)) = make_uint4(e[4], e[5], e[6], e[7]);
     };
 
     // One step = one tile.  The two accumulation chains of a tile (query sets 0 and 1) are issued one after
@@ -142,48 +129,63 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
         k1[s] = umed3(k0[s], k1[s], (uint32_t)key);
         k0[s] = min(k0[s], (uint32_t)key);
     };
-    // the start values of a tile's accumulators: register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half
-    auto words = [&](int buf) {
-        v16i c;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&s_c[buf][8 * g + 4 * half]);
-            c[4 * g] = (int)v.x; c[4 * g + 1] = (int)v.y; c[4 * g + 2] = (int)v.z; c[4 * g + 3] = (int)v.w;
-        }
-        return c;
-    };
     // the chain of query set s over the tile in A, with the updates of set 1 - s (accumulator `done`)
-    auto chain = [&](int s, v16i &acc, const v16i &start, const v4i (&A)[8], const v16i &done) {
+    // (gap(ks): further work for the issue gap after MFMA ks)
+    auto chain = [&](int s, v16i &acc, const v16i &start, v4i (&A)[8], const v16i &done, auto gap) {
 #pragma unroll
         for (int ks = 0; ks < 8; ks++) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[ks], B[s][ks], ks == 0 ? start : acc, 0, 0, 0);
             update(1 - s, done[2 * ks]);
             update(1 - s, done[2 * ks + 1]);
+            gap(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto operand = [&](int buf, int ks) {
+        return *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
+    };
 
-    v16i acc0, acc1;
+    v16i acc0, acc1, start;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc0[r] = acc1[r] = -1;  // "tile -1": keys that change nothing
-    // tile t+1 is expanded at the start of step t (from packed words loaded during step t-1), while the operand
-    // reads of tile t are in flight
-    if (ntiles > 0) stage(0, 0, load_packed(0));
-    uint32_t next = ntiles > 1 ? load_packed(1) : 0u;
+    for (int r = 0; r < 16; r++) {
+        acc0[r] = acc1[r] = -1;  // "tile -1": keys that change nothing
+        // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
+        start[r] = kKeyBias + j_lo + (r & 3) + 8 * (r >> 2) + 4 * half;
+    }
+    // Three tiles live in LDS.  Step t expands tile t+2 (from packed words loaded during step t-1), runs the two
+    // chains of tile t from registers and, as chain 1 releases them one by one, refills the operand registers
+    // with tile t+1 (expanded during step t-1): the operand reads of a step are in flight during the MFMAs of
+    // the step before, nothing is read right after the block barrier.
+    if (ntiles > 0) stage(0, load_packed(0));
+    if (ntiles > 1) stage(1, load_packed(1));
+    uint32_t next = ntiles > 2 ? load_packed(2) : 0u;
     __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
-        const int buf = t & 1;
-        v4i A[8];
+    v4i A[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++)
-            A[ks] = *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
-        const v16i start = words(buf);
-        if (t + 1 < ntiles) stage(buf ^ 1, t + 1, next);  // block-uniform
-        if (t + 2 < ntiles) next = load_packed(t + 2);
+    for (int ks = 0; ks < 8; ks++) A[ks] = operand(0, ks);
+    int bcur = 0;  // t % 3
+    for (int t = 0; t < ntiles; t++) {
+        const int bnext = bcur == 2 ? 0 : bcur + 1, bnext2 = bnext == 2 ? 0 : bnext + 1;
+        const bool more = t + 1 < ntiles;             // block-uniform
+        if (t + 2 < ntiles) stage(bnext2, next);
+        if (t + 3 < ntiles) next = load_packed(t + 3);
+        if (t == ntiles - 1) {
+            // rows past the share (their bytes are some other train's): keys above every real one
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (start[r] - kKeyBias >= j_hi) start[r] = (int)kKeyNone + kKeyBias;
+        }
         __builtin_amdgcn_sched_barrier(0);
-        chain(0, acc0, start, A, acc1);
-        chain(1, acc1, start, A, acc0);
-        __syncthreads();
+        chain(0, acc0, start, A, acc1, [](int) {});
+        chain(1, acc1, start, A, acc0, [&](int ks) {
+            if (more) A[ks] = operand(bnext, ks);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; r++) start[r] += KNN_TILE;
+        // block barrier for the LDS tiles only: __syncthreads() would also wait for the packed words of tile
+        // t+3, a global load that is meant to stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        bcur = bnext;
     }
     // set 1 of the last tile
     if (ntiles > 0) {
@@ -197,11 +199,11 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
         const uint32_t o0 = __shfl_xor(k0[s], 32), o1 = __shfl_xor(k1[s], 32);
         const uint32_t n0 = min(k0[s], o0);
         const uint32_t n1 = min(max(k0[s], o0), min(k1[s], o1));
-        // key -> (distance << 16) | train index; keys of rows past the share (and the initial ones) mean "none"
+        // key -> (distance << 16) | train index
         auto finish = [&](uint32_t k) {
-            if (k >= 0x7fffffffu) return 0xffffffffu;
-            const uint32_t dpart = k / kKeyScale, idx = k - dpart * kKeyScale;
-            return ((dpart + pq[s] - 512u) << 16) | idx;
+            if (k >= kKeyNone) return 0xffffffffu;
+            const uint32_t d = k / (uint32_t)kKeyScale, idx = k - d * (uint32_t)kKeyScale;
+            return (d << 16) | idx;
         };
         const int q = qbase + wave * KNN_QPW + 32 * s + col;
         if (half == 0 && q < nq)
