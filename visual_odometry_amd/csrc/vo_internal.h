@@ -12,7 +12,7 @@ constexpr int kWave = 64;
 constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
 constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
 constexpr int kResizeRowPad = 32;  // rows of a resize tile: the row tables of the pyramid are padded to it
-constexpr int kKnnSplits = 4;      // train-set splits per query block
+constexpr int kKnnSplits = 2;      // train-set splits per query block
 constexpr int kFBorder = 31;       // ORB edgeThreshold
 constexpr int kTileW = 128, kTileH = 32;  // tile of the fused image kernel
 constexpr int kTileCap = kTileW * kTileH / 4;  // corners one tile can emit (3x3 strict maxima: one per 2x2 block)
