@@ -29,6 +29,7 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 constexpr int kKeyScale = 6144;
 constexpr int kKeyBias = 256 * (kKeyScale / 2);  // what the products of 256 equal bits sum to
 static_assert(kKeyScale == 2 * 64 * 48, "train bytes +-64, query bytes -+48");
+static_assert(kKeyScale >= VO_MAX_FEATURES_LIMIT, "the key scale must exceed every train index");
 constexpr uint32_t kKeyNone = 0x7e000000u;       // keys at or above: no train
 
 // bits 4i .. 4i+3 of x spread to bit `pos` of four bytes (bit 4i+j in byte j): the multiplier puts bit j at 8j
