@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 // (vo_cfg.max_features <= 6144) -- and it is twice the magnitude of the byte product of the MFMA operands,
 // 64 * 48 = 6144 / 2.
 constexpr int kKeyScale = 6144;
-constexpr int kKeyBias = 256 * (kKeyScale / 2);  // what the products of 256 equal bits sum to
+constexpr int kKeyBias = 256 * (kKeyScale / 2);  // 256 equal bits: the products sum to minus this
 static_assert(kKeyScale == 2 * 64 * 48, "train bytes +-64, query bytes -+48");
 static_assert(kKeyScale >= VO_MAX_FEATURES_LIMIT, "the key scale must exceed every train index");
 constexpr uint32_t kKeyNone = 0x7e000000u;       // keys at or above: no train
