@@ -254,7 +254,8 @@ def main():
             "metric": "frames/sec (detect+match+RANSAC pose) @1280x720, 2000 kp",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int32 (image, match), f32 (Harris, angle), f64 (RANSAC)",
+            "vs_baseline": None, "dtype": "u8/int32 (image), %s (match), f32 (Harris, angle), f64 (RANSAC)" %
+                     ("int8 MFMA -> int32" if args.matcher == "mfma" else "u32 xor/popcount"),
             "data": "synthetic",
             "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
                                    ("orb8level" if levels else "fast1level"),
