@@ -351,6 +351,23 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
                                          int src_stride, int width, int height, const FeTile &tile, GrayCoeffs c)
 {
     const int tid = threadIdx.x;
+    if constexpr (CN == 1 && PATH == FE_INSIDE) {
+        // gray input, tile and apron inside the image: the rows are copied as 16-byte pieces (4-byte aligned in
+        // global memory, 16-byte aligned in LDS), one piece per thread
+        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR;
+        static_assert(NP <= FE_THREADS && FE_PITCH % 16 == 0, "one 16-byte piece per thread");
+        static_assert(FE_SROWS * FE_PITCH / 16 <= FE_THREADS, "one 16-byte piece of the score tile per thread");
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const int i = min(tid, NP - 1);
+        const int tr = i / PPR, tp = i - tr * PPR;
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(img + (size_t)(tile.y0 - 4 + tr) * src_stride +
+                                                                (tile.x0 - 4 + 16 * tp));
+        if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
+        if (tid < 3) s_counters[tid] = 0;
+        FE_STAMP(1);
+        if (tid < NP) *reinterpret_cast<uint4 *>(&s_gray[tr * FE_PITCH + 16 * tp]) = make_uint4(v.x, v.y, v.z, v.w);
+        return;
+    }
     FePre<CN> pre[FE_TPT];
     bool packed[FE_TPT];
     int at[FE_TPT];
