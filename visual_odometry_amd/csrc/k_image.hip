@@ -368,6 +368,34 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
         if (tid < NP) *reinterpret_cast<uint4 *>(&s_gray[tr * FE_PITCH + 16 * tp]) = make_uint4(v.x, v.y, v.z, v.w);
         return;
     }
+    if constexpr (CN == 1 && PATH == FE_BORDER) {
+        // gray input, border tile of an aligned image: the same 16-byte pieces with the row reflected; a piece
+        // that crosses the left or right image edge is gathered byte by byte
+        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR;
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const int i = min(tid, NP - 1);
+        const int tr = i / PPR, tp = i - tr * PPR;
+        const uint8_t *row = img + (size_t)reflect101_near(tile.y0 - 4 + tr, height) * src_stride;
+        const int xb = tile.x0 - 4 + 16 * tp;
+        uint32_t w[4];
+        if (xb >= 0 && xb + 16 <= width) {
+            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(row + xb);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                w[q] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    w[q] |= (uint32_t)row[reflect101_near(xb + 4 * q + j, width)] << (8 * j);
+            }
+        }
+        if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
+        if (tid < 3) s_counters[tid] = 0;
+        FE_STAMP(1);
+        if (tid < NP) *reinterpret_cast<uint4 *>(&s_gray[tr * FE_PITCH + 16 * tp]) = make_uint4(w[0], w[1], w[2], w[3]);
+        return;
+    }
     FePre<CN> pre[FE_TPT];
     bool packed[FE_TPT];
     int at[FE_TPT];
