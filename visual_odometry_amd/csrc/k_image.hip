@@ -408,7 +408,8 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
         at[u] = tr * FE_PITCH + tq * 4;
         if (i < FE_TASKS) packed[u] = fe_issue<CN, PATH>(pre[u], img, src_stride, width, height, tile, tr, tq);
     }
-    for (int i = tid; i < FE_SROWS * (FE_PITCH / 4); i += FE_THREADS) reinterpret_cast<uint32_t *>(s_score)[i] = 0;
+    static_assert(FE_SROWS * FE_PITCH / 16 <= FE_THREADS && FE_PITCH % 16 == 0, "one 16-byte piece of the score tile per thread");
+    if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
     if (tid < 3) s_counters[tid] = 0;
     FE_STAMP(1);
 #pragma unroll
