@@ -2,8 +2,11 @@
 """HBM bytes per launch of the image stages from a FETCH_SIZE / WRITE_SIZE summary (pmcstats.py output of the two
 --pmc passes of `python3 bench.py --cpu-frames 0 --steps 3 --warmup 1`): writes the JSON bench.py reads for
 `roofline.traffic`.  FETCH_SIZE is doubled for the kernels whose loads are 16 bytes per lane (the level-0 tile
-kernel on BGRA input, the resize kernel), as the counter tallies 128-byte requests at 64 bytes on gfx950; kernels
-with narrower loads are left uncalibrated (bytes = null, raw counters kept)."""
+kernel on BGRA input, the resize kernel), as the counter tallies 128-byte requests at 64 bytes on gfx950.  The
+gray-input instantiation of the tile kernel is taken as read: run on a gray copy of the BGRA frames (same tiles,
+a quarter of the bytes) it reads 0.483 of the BGRA run's raw value, not 0.25, and 1.37 x the plane's bytes, which
+is the apron re-read its 128x32 tiles imply (tools/calib_fetch.py, profiles/calib.sh).  Other kernels with narrow
+loads are left uncalibrated (bytes = null)."""
 import json
 import sys
 
@@ -40,8 +43,11 @@ def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
     if d:
         n = d["FETCH_SIZE"][1] // max(1, find("k_frontendILi4E")["FETCH_SIZE"][1])
         stages["frontend_upper_levels"] = {
-            "bytes": None, "raw_fetch_bytes": d["FETCH_SIZE"][0] * 1024 * n, "write_bytes": d["WRITE_SIZE"][0] * 1024 * n,
-            "note": f"{n} launches; 4-byte loads: FETCH_SIZE is uncalibrated for this width, raw value kept"}
+            "bytes": (d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024 * n,
+            "fetch_bytes": d["FETCH_SIZE"][0] * 1024 * n, "write_bytes": d["WRITE_SIZE"][0] * 1024 * n,
+            "note": f"{n} launches; FETCH_SIZE as read + WRITE_SIZE: on 1-byte gray input the counter reads the staged "
+                    "bytes themselves (calibrated against the BGRA instantiation on the same tiles, "
+                    "r01_fetch_calibration.txt)"}
     # vector-ALU occupancy of the same kernels: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, so
     # busy = 4 * count / (1024 SIMDs * 2.4 GHz * average kernel duration from the kernel trace)
     if sq_path and kstats_path:
