@@ -13,11 +13,21 @@ namespace vo {
 // =====================================================================
 
 constexpr int TA_THREADS = 1024;
+constexpr int TA_PER_THREAD = (VO_MAX_FEATURES_LIMIT + TA_THREADS - 1) / TA_THREADS;  // key points per thread
+constexpr int TA_MAX_FRAMES = 64;  // frames per stream whose scalars are staged at once
+static_assert(VO_MAX_FEATURES_LIMIT <= 8192, "match and key point indices are packed as 13 + 13 bits");
 
 // For frame f of stream s (batch index b = s*frames + f):
 //   age[curr][train] = age[prev][query] + 1 for every match, later matches
 //   overwriting earlier ones, all other ages 0; flag[b] = 1 when more than 80
 //   matches exist and at least 50 of them have age >= 3.
+// The frames of a stream depend on each other through the ages only, so the
+// chain a frame waits on is kept short: the per-frame scalars of a group of
+// frames are staged in LDS before the loop, the ages of the newest frame stay
+// in LDS for the next one, a frame's matches are loaded (into registers) while
+// the frame before it is still being finished, and the winning match of a key
+// point carries its query index (key = match index << 13 | query), so nothing
+// is read back from global memory inside the loop.
 __global__ __launch_bounds__(TA_THREADS) void k_track_ages(const vo_match *__restrict__ final_m,
                                                            const int *__restrict__ info, int kp_stride,
                                                            const int *__restrict__ q_slot,
@@ -27,51 +37,98 @@ __global__ __launch_bounds__(TA_THREADS) void k_track_ages(const vo_match *__res
                                                            int *__restrict__ filter_flag)
 {
     __shared__ int s_winner[VO_MAX_FEATURES_LIMIT];
-    __shared__ int s_cnt;
-    const int s = blockIdx.x, tid = threadIdx.x;
-    for (int f = 0; f < frames; f++) {
-        const int b = s * frames + f;
-        const int ts = t_slot[b];
-        int *age_c = ages + (size_t)ts * kp_stride;
-        const int n_curr = nkp[ts];
-        if (!has_prev[b]) {
-            for (int i = tid; i < kp_stride; i += TA_THREADS) age_c[i] = 0;
-            if (tid == 0) filter_flag[b] = 0;
-            __syncthreads();
-            continue;
-        }
-        const int qs = q_slot[b];
-        const int *age_p = ages + (size_t)qs * kp_stride;
-        const int n_prev = nkp[qs];
-        const int n = info[b * 4 + 3];
-        const vo_match *m = final_m + (size_t)b * kp_stride;
-        for (int i = tid; i < kp_stride; i += TA_THREADS) s_winner[i] = -1;
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += TA_THREADS) {
-            const int t = m[i].train;
-            if (t >= 0 && t < n_curr) atomicMax(&s_winner[t], i);
+    __shared__ int s_age[VO_MAX_FEATURES_LIMIT];  // ages of the frame finished last (slot s_age_slot)
+    __shared__ int s_ts[TA_MAX_FRAMES], s_qs[TA_MAX_FRAMES], s_hp[TA_MAX_FRAMES], s_n[TA_MAX_FRAMES],
+        s_ncurr[TA_MAX_FRAMES], s_nprev[TA_MAX_FRAMES], s_cnt[TA_MAX_FRAMES];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+
+    for (int i = tid; i < kp_stride; i += TA_THREADS) s_winner[i] = -1;
+    int age_slot = -1;  // the slot whose ages s_age holds (block-uniform)
+
+    for (int g0 = 0; g0 < frames; g0 += TA_MAX_FRAMES) {
+        const int gn = min(frames - g0, TA_MAX_FRAMES);
+        __syncthreads();  // the previous group's scalars are no longer read
+        if (tid < gn) {
+            const int b = s * frames + g0 + tid;
+            const int ts = t_slot[b], hp = has_prev[b], qs = hp ? q_slot[b] : ts;
+            s_ts[tid] = ts; s_qs[tid] = qs; s_hp[tid] = hp;
+            s_n[tid] = hp ? min(info[b * 4 + 3], kp_stride) : 0;
+            s_ncurr[tid] = nkp[ts]; s_nprev[tid] = nkp[qs];
+            s_cnt[tid] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < kp_stride; i += TA_THREADS) {
-            const int w = s_winner[i];
-            int a = 0;
-            if (w >= 0) {
-                const int q = m[w].query;
-                a = ((q >= 0 && q < n_prev) ? age_p[q] : 0) + 1;
+
+        // matches of a frame as (train, query) per thread; train = -1: none
+        int tr[TA_PER_THREAD], qu[TA_PER_THREAD];
+        auto load_matches = [&](int fl) {
+            const vo_match *m = final_m + (size_t)(s * frames + g0 + fl) * kp_stride;
+            const int n = s_n[fl];
+#pragma unroll
+            for (int k = 0; k < TA_PER_THREAD; k++) {
+                const int i = tid + k * TA_THREADS;
+                tr[k] = -1; qu[k] = 0;
+                if (i < n) { tr[k] = m[i].train; qu[k] = m[i].query; }
             }
-            age_c[i] = a;
+        };
+        load_matches(0);
+
+        for (int fl = 0; fl < gn; fl++) {
+            const int ts = s_ts[fl], qs = s_qs[fl], n_curr = s_ncurr[fl], n_prev = s_nprev[fl];
+            const bool hp = s_hp[fl] != 0;
+            int *age_c = ages + (size_t)ts * kp_stride;
+            // the ages of the query frame: in LDS already when it is the frame finished last
+            if (hp && qs != age_slot) {  // block-uniform
+                __syncthreads();  // the frame before may still be counting over s_age
+                const int *age_p = ages + (size_t)qs * kp_stride;
+                for (int i = tid; i < kp_stride; i += TA_THREADS) s_age[i] = age_p[i];
+            }
+            if (hp) {
+#pragma unroll
+                for (int k = 0; k < TA_PER_THREAD; k++) {
+                    const int t = tr[k], q = qu[k];
+                    if (t >= 0 && t < n_curr) {
+                        const int qf = (q >= 0 && q < n_prev) ? q : 8191;  // 8191: no such key point
+                        atomicMax(&s_winner[t], ((tid + k * TA_THREADS) << 13) | qf);
+                    }
+                }
+            }
+            __syncthreads();
+            int a[TA_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < TA_PER_THREAD; k++) {
+                const int i = tid + k * TA_THREADS;
+                a[k] = 0;
+                if (hp && i < kp_stride) {
+                    const int w = s_winner[i];
+                    if (w >= 0) {
+                        const int q = w & 8191;
+                        a[k] = (q < n_prev ? s_age[q] : 0) + 1;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < TA_PER_THREAD; k++) {
+                const int i = tid + k * TA_THREADS;
+                if (i < kp_stride) { s_age[i] = a[k]; age_c[i] = a[k]; s_winner[i] = -1; }
+            }
+            age_slot = ts;
+            __syncthreads();
+            int mature = 0;
+            if (hp) {
+#pragma unroll
+                for (int k = 0; k < TA_PER_THREAD; k++) {
+                    const int t = tr[k];
+                    mature += (t >= 0 && t < n_curr && s_age[t] >= 3);
+                }
+            }
+            // the next frame's matches are on their way while this frame's count is summed
+            if (fl + 1 < gn) load_matches(fl + 1);
+            for (int o = 32; o > 0; o >>= 1) mature += __shfl_xor(mature, o);
+            if (lane == 0 && mature) atomicAdd(&s_cnt[fl], mature);
         }
         __syncthreads();
-        int mature = 0;
-        for (int i = tid; i < n; i += TA_THREADS) {
-            const int t = m[i].train;
-            mature += (t >= 0 && t < n_curr && age_c[t] >= 3);
-        }
-        if (mature) atomicAdd(&s_cnt, mature);
-        __syncthreads();
-        if (tid == 0) filter_flag[b] = (n > 80 && s_cnt >= 50) ? 1 : 0;
-        __syncthreads();
+        if (tid < gn) filter_flag[s * frames + g0 + tid] = (s_hp[tid] && s_n[tid] > 80 && s_cnt[tid] >= 50) ? 1 : 0;
     }
 }
 
