@@ -106,6 +106,35 @@ def test_batch_pipeline_multiview_filter_engages(ctx, oracle):
     assert dropped > 0
 
 
+def test_batch_pipeline_long_stream_launch(oracle):
+    """66 frames of one stream in one launch (the track-age kernel stages the frame scalars in groups of 64),
+    twice, so that ages cross both the group and the launch boundary; second stream offset by one frame."""
+    from oracle.pipeline import OracleStream
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    S, F, NB, D = 2, 66, 2, 5
+    seq = synth.make_sequence(cam, D, seed=31, channels=1)
+    walk = list(range(D)) + list(range(D - 2, 0, -1))  # 0 1 2 3 4 3 2 1 | 0 ...
+    order = [[walk[(s + k) % len(walk)] for k in range(F * NB)] for s in range(S)]
+    refs = [OracleStream(None, 500, 20) for _ in range(S)]
+    c = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=500, max_batch=S * F)
+    try:
+        c.batch_configure(cam.width, cam.height, 1, n_streams=S, frames_per_stream=F, max_features=500)
+        dropped = 0
+        for nb in range(NB):
+            frames = np.stack([seq["frames"][order[s][nb * F + f]] for s in range(S) for f in range(F)])
+            c.batch_submit(frames)
+            res = c.batch_wait()
+            for s in range(S):
+                for f in range(F):
+                    r = refs[s].process(seq["frames"][order[s][nb * F + f]])
+                    _compare_frame(c, res, s * F + f, r, pose=False)
+                    dropped += len(r["matches"]) - len(r["tracked"])
+        assert dropped > 0
+    finally:
+        c.close()
+
+
 def test_batch_reset_makes_first_frame(ctx, oracle):
     cam = synth.CONFIG_CAMERAS["vga"]
     seq = synth.make_sequence(cam, 2, seed=77, channels=3)
