@@ -130,6 +130,30 @@ int vo_set_matcher(vo_ctx *ctx, int kind);
 int vo_knn2_hamming(vo_ctx *ctx, const uint8_t *query, int n_query,
                     const uint8_t *train, int n_train, vo_knn2 *out);
 
+/* vo_knn2_hamming for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It
+ * has no counterpart in the reference (whose cv::BFMatcher allocates freely,
+ * src/feature_matcher.cpp:27-31).  Same kernels and results as vo_knn2_hamming,
+ * but no vo_ctx: every buffer beyond the caller's inputs and output (descriptor
+ * slots, per-split partial lists, merged records, control words; 385 KiB) is a
+ * static device array inside the library, present on every GPU the process
+ * uses.  The call makes no hipMalloc / hipFree and creates no stream or event.
+ *   device      GPU to run on (made current);
+ *   hip_stream  a hipStream_t to enqueue on, NULL = the device's default stream;
+ *   query/train/out  host or device memory of that GPU (copies use
+ *               hipMemcpyDefault); with wait == 0 they must stay valid until the
+ *               stream has run the work;
+ *   wait        non-zero: return after the stream has finished the call.
+ * n_query and n_train may not exceed VO_KNN2_STATIC_MAX (VO_ERR_ARG otherwise;
+ * vo_static_last_error() holds the message).  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (two threads, two streams) race;
+ * serialise them. */
+#define VO_KNN2_STATIC_MAX 4096
+int vo_knn2_hamming_static(int device, void *hip_stream, const uint8_t *query, int n_query,
+                           const uint8_t *train, int n_train, vo_knn2 *out, int wait);
+/* message of the calling thread's last failed vo_knn2_hamming_static call */
+const char *vo_static_last_error(void);
+
 /* cv::findFundamentalMat(p1, p2, FM_RANSAC, threshold, confidence, mask)
  * with max_iters (OpenCV default 1000) and cv::RNG seed 2^64-1.
  * p1, p2: n x 2 float32; mask: n bytes; F: 9 doubles row-major.

@@ -73,6 +73,8 @@ EXPORTS = {
     "vo_blur7": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "vo_detect": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "vo_knn2_hamming": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
+    "vo_knn2_hamming_static": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
+    "vo_static_last_error": (C.c_char_p, []),
     "vo_find_fundamental_ransac": (C.c_int, [_P, _P, _P, C.c_int, C.c_double, C.c_double, C.c_int,
                                              _P, _P, _P, _P]),
     "vo_match_features": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, _P, _P]),
@@ -133,6 +135,18 @@ def load():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def knn2_static(query: np.ndarray, train: np.ndarray, device: int = 0) -> np.ndarray:
+    """vo_knn2_hamming_static: the kNN-2 search without a context and without any allocation in the library."""
+    lib = load()
+    query = np.ascontiguousarray(query, np.uint8).reshape(-1, 32)
+    train = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+    out = np.zeros(len(query), KNN_DTYPE)
+    rc = lib.vo_knn2_hamming_static(device, None, _ptr(query), len(query), _ptr(train), len(train), _ptr(out), 1)
+    if rc != VO_OK:
+        raise VoError(rc, lib.vo_static_last_error().decode())
+    return out
 
 
 class Context:
