@@ -22,12 +22,18 @@ MATCH_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("distance", "<f4"),
                         ("px", "<f4"), ("py", "<f4"), ("cx", "<f4"), ("cy", "<f4")])
 
 
+_SORT_LIB_PATH = os.path.join(_HERE, "libvo_oracle_stdsort.so")
+
+
 def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvo_oracle.so"],
                               stdout=subprocess.DEVNULL)
+    cpp = os.path.join(_HERE, "vo_oracle_stdsort.cpp")
+    if force or not os.path.exists(_SORT_LIB_PATH) or os.path.getmtime(cpp) > os.path.getmtime(_SORT_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libvo_oracle_stdsort.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -114,6 +120,28 @@ def fast(g: np.ndarray, thr: int) -> np.ndarray:
     out = np.zeros(cap, KP_DTYPE)
     n = lib().ora_fast(_p(g), w, h, w, thr, _p(out), cap)
     return out[:n].copy()
+
+
+def select_top(kps: np.ndarray, width: int, max_features: int) -> np.ndarray:
+    """Canonical top-N of raster-ordered FAST corners: (response desc, raster asc)."""
+    k = np.ascontiguousarray(kps, KP_DTYPE).copy()
+    n = lib().ora_select_top(_p(k), len(k), width, max_features)
+    return k[:n].copy()
+
+
+_sort_lib = None
+
+
+def select_top_stdsort(kps: np.ndarray, max_features: int) -> np.ndarray:
+    """The reference's literal std::sort + resize (src/feature_detector.cpp:62-68), libstdc++."""
+    global _sort_lib
+    if _sort_lib is None:
+        if not os.path.exists(_SORT_LIB_PATH):
+            build()
+        _sort_lib = C.CDLL(_SORT_LIB_PATH)
+    k = np.ascontiguousarray(kps, KP_DTYPE).copy()
+    n = _sort_lib.ora_select_top_stdsort(_p(k), len(k), max_features)
+    return k[:n].copy()
 
 
 def blur7(g: np.ndarray) -> np.ndarray:

@@ -66,8 +66,11 @@ int ora_fast(const uint8_t *img, int w, int h, int stride, int thr,
  * max_features the raster order is left untouched, as in the reference. */
 int ora_select_top(ora_kp *kps, int n, int w, int max_features);
 
-/* the same selection done literally: std::sort-like unstable ordering is
- * replaced by a stable sort so that only the tie order may differ. */
+/* the same truncation done literally (vo_oracle_stdsort.cpp, built into
+ * libvo_oracle_stdsort.so with g++): std::sort with the reference's comparator
+ * on the raster-ordered corners, then resize.  Used to measure how far the
+ * canonical order above is from what libstdc++ leaves. */
+int ora_select_top_stdsort(ora_kp *kps, int n, int max_features);
 
 /* KeyPointsFilter::runByImageBorder(kps, size, 31) as run inside
  * ORB::compute (reference src/feature_detector.cpp:73). Order preserved. */
