@@ -30,25 +30,51 @@ VALU_PEAK_GLOPS = 39321.6    # 256 CU x 64 lanes x 2.4 GHz, 32-bit integer lane-
 MFMA_I8_PEAK_TOPS = 5033.2   # dense int8 MFMA: 1024 SIMDs x 1024 MAC/clk x 2 x 2.4 GHz (twice the bf16 rate)
 
 
-def pingpong(n):
-    """0,1,...,n-1,n-2,...,1 : every consecutive pair (cyclically) is one frame apart."""
-    return list(range(n)) + list(range(n - 2, 0, -1))
+HARD_SCENE_MOVERS = 30       # independently moving rectangles of the hard scene (>= 30 % of the ratio-test
+                             # survivors then violate the camera's epipolar geometry)
 
 
-def build_inputs(streams, frames, seed):
+def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0):
+    """`streams` independent HD720 BGRA + depth streams (stream s is rendered from seed + s: its own scene,
+    texture and noise), `frames` consecutive frames each, walking forth and back over frames/2 + 1 camera
+    positions so that a launch can be repeated.  Returns the camera, the frames and depth planes in batch order
+    and, per stream, the ground-truth T_prev_from_curr of each frame."""
     from visual_odometry_amd import synth
     cam = synth.CONFIG_CAMERAS["hd720"]
-    n_distinct = frames // 2 + 1
-    # strong depth relief keeps the pose problem well posed (a nearly planar scene makes the DLT
-    # initialisation of the PnP refinement ambiguous)
-    seq = synth.make_sequence(cam, n_distinct, seed=seed, channels=4, scene=synth.Scene(seed, relief=2.0))
-    order = pingpong(n_distinct)
-    assert len(order) == frames
-    f = np.stack([seq["frames"][i] for i in order])
-    d = np.stack([seq["depth"][i] for i in order])
-    # ground-truth T_prev_from_curr of every frame of a stream (frame 0 follows the last frame of the cycle)
-    truth = [synth.relative_pose(seq["poses"][order[k - 1]], seq["poses"][order[k]]) for k in range(frames)]
-    return cam, np.concatenate([f] * streams), np.concatenate([d] * streams), truth
+    f, d, truth = synth.make_pingpong_batch(cam, streams, frames, seed, channels=4, relief=relief, movers=movers,
+                                            workers=workers)
+    return cam, f, d, truth
+
+
+def kernel_source_hash():
+    """SHA-256 over the kernel sources: profile-derived numbers are only quoted for the sources they were
+    measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "visual_odometry_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "visual_odometry_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def committed_traffic(frames_per_launch):
+    """(per-stage counters, description of where they come from).  rocprofv3 cannot run inside this process, so
+    HBM bytes per launch come from the newest PMC summary under profiles/ -- and only if it was taken at this
+    launch size on exactly these kernel sources."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not cands:
+        return {}, "none: no profiles/rNN_traffic.json"
+    path = cands[-1]
+    rel = os.path.relpath(path, ROOT)
+    tj = json.load(open(path))
+    if tj.get("frames_per_launch") != frames_per_launch:
+        return {}, f"refused: {rel} was taken at {tj.get('frames_per_launch')} frames per launch"
+    if tj.get("source_hash") != kernel_source_hash():
+        return {}, f"refused: {rel} was taken on other kernel sources (hash mismatch)"
+    return tj["stages"], f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ passes, kernel sources {tj['source_hash'][:12]})"
 
 
 def cpu_baseline(cam, frames, depth, n_frames, max_features, orb_levels):
@@ -67,7 +93,7 @@ def cpu_baseline(cam, frames, depth, n_frames, max_features, orb_levels):
 def _cpu_worker(job):
     """One host core: its own stream (rendered here), the oracle pipeline over n_frames; returns (frames, seconds)."""
     seed, frames, n_frames, max_features, orb_levels = job
-    cam, f, d, _ = build_inputs(1, frames, seed)
+    cam, f, d, _ = build_inputs(1, frames, seed)  # its own scene
     from oracle.pipeline import OracleStream
     ref = OracleStream((cam.fx, cam.fy, cam.cx, cam.cy), max_features, 20, orb_levels=orb_levels)
     ref.process(f[0], d[0])
@@ -108,6 +134,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=192, help="frames timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=16,
                     help="host cores for the all-core CPU baseline (one stream each; 0 = skip; capped at the CPU count)")
+    ap.add_argument("--render-workers", type=int, default=16, help="processes rendering the synthetic streams")
+    ap.add_argument("--hard-scene", type=int, default=1,
+                    help="also run the same launch on streams with independently moving objects (0 = skip)")
+    ap.add_argument("--cpu-fast", type=int, default=1,
+                    help="also time the CPU baseline of the other detector (the one-level FAST sequence the "
+                         "reference node runs) for the record (0 = skip)")
     args = ap.parse_args()
 
     # the all-core CPU baseline runs first, in child processes started before this process initialises the GPU
@@ -139,12 +171,15 @@ def main():
     S, F = args.streams // NC, args.frames   # streams per context
     Bc = S * F                               # frames per context per step
     B = Bc * NC                              # frames per step per GPU
-    cam, frames_h, depth_h, truth = build_inputs(S, F, seed=2000 + rank)
+    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1))
+    # every stream of every context and rank has its own seed: 2000 + 1000 * rank + stream
+    inputs = [build_inputs(S, F, seed=2000 + 1000 * rank + S * k, workers=render_workers) for k in range(NC)]
+    cam, frames_h, depth_h, truth = inputs[0]
     H, W, C = cam.height, cam.width, 4
     K = (cam.fx, cam.fy, cam.cx, cam.cy)
-    # every context owns its own copy of the input frames in HBM
-    frames_d = [torch.from_numpy(frames_h).cuda() for _ in range(NC)]
-    depth_d = [torch.from_numpy(depth_h).cuda() for _ in range(NC)]
+    frames_d = [torch.from_numpy(i[1]).cuda() for i in inputs]
+    depth_d = [torch.from_numpy(i[2]).cuda() for i in inputs]
+    truths = [i[3] for i in inputs]
     ctxs = []
     levels = 8 if args.detector == "orb" else 0
     cap = args.features + (64 if levels else 0)  # room for boundary ties of the per-level ranking
@@ -156,43 +191,77 @@ def main():
         ctxs.append(c)
     ctx = ctxs[0]
 
-    def step():
-        # all contexts in flight at once: their kernels interleave on the GPU
-        for c, fd, dd in zip(ctxs, frames_d, depth_d):
-            c.batch_submit_ptr(fd.data_ptr(), W * C, W * C * H, dd.data_ptr(), W, W * H)
-        out = [c.batch_wait() for c in ctxs]
-        return np.concatenate(out)
-
-    for _ in range(args.warmup):
-        res = step()
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
     from visual_odometry_amd import shard
-    fps = shard.aggregate_fps(B * args.steps, elapsed, dist, "cuda")
-    elapsed = shard.max_over_ranks(elapsed, dist, "cuda")
 
-    # per-kernel durations with HIP events on the library's own stream
-    # (context 0 alone, so that one launch's duration is not stretched by another context's kernels)
-    ctx.batch_set_timing(True)
-    acc = {}
-    reps = 5
-    for _ in range(reps):
-        ctx.batch_submit_ptr(frames_d[0].data_ptr(), W * C, W * C * H, depth_d[0].data_ptr(), W, W * H)
-        ctx.batch_wait()
-        for k, v in ctx.batch_timing().items():
-            acc[k] = acc.get(k, 0.0) + v / reps
-    ctx.batch_set_timing(False)
+    def measure(fds, dds, steps, warmup, reps=5):
+        """warmup + exactly `steps` timed steps over the given device frames (one tensor per context), then the
+        per-kernel durations of one context's launch from HIP events on the library's own stream."""
+        def step():
+            # all contexts in flight at once: their kernels interleave on the GPU
+            for c, fd, dd in zip(ctxs, fds, dds):
+                c.batch_submit_ptr(fd.data_ptr(), W * C, W * C * H, dd.data_ptr(), W, W * H)
+            return np.concatenate([c.batch_wait() for c in ctxs])
+
+        r = None
+        for _ in range(warmup):
+            r = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        fps_ = shard.aggregate_fps(B * steps, dt, dist, "cuda")
+        dt = shard.max_over_ranks(dt, dist, "cuda")
+        # (context 0 alone, so that one launch's duration is not stretched by another context's kernels)
+        ctx.batch_set_timing(True)
+        acc_ = {}
+        for _ in range(reps):
+            ctx.batch_submit_ptr(fds[0].data_ptr(), W * C, W * C * H, dds[0].data_ptr(), W, W * H)
+            ctx.batch_wait()
+            for k, v in ctx.batch_timing().items():
+                acc_[k] = acc_.get(k, 0.0) + v / reps
+        ctx.batch_set_timing(False)
+        return fps_, dt, r, acc_
+
+    fps, elapsed, res, acc = measure(frames_d, depth_d, args.steps, args.warmup)
+
+    # the same launch on a hard scene: every stream has independently moving objects, so a third and more of the
+    # ratio-test survivors are outliers for the F-RANSAC (hundreds of 7-point iterations instead of a handful)
+    # and the PnP RANSAC sees what slips through.  Reported beside the headline, never as `value`.
+    hard = None
+    if args.hard_scene:
+        hin = [build_inputs(S, F, seed=52000 + 1000 * rank + S * k, movers=HARD_SCENE_MOVERS, workers=render_workers)
+               for k in range(NC)]
+        hf = [torch.from_numpy(i[1]).cuda() for i in hin]
+        hd = [torch.from_numpy(i[2]).cuda() for i in hin]
+        for c in ctxs:
+            c.batch_reset()
+        h_fps, h_dt, h_res, h_acc = measure(hf, hd, max(3, args.steps // 2), max(2, args.warmup), reps=3)
+        m = h_res["n_ratio"] > 0
+        hard = {
+            "value": h_fps, "unit": "frames/s", "steps": max(3, args.steps // 2),
+            "ms_per_step": 1e3 * h_dt / max(3, args.steps // 2),
+            "scene": f"{HARD_SCENE_MOVERS} independently moving textured rectangles per stream, own scene per stream",
+            "stage_ms_per_launch": {k: round(v, 4) for k, v in h_acc.items()},
+            "mean_keypoints": float(h_res["n_keypoints"].mean()),
+            "mean_ratio_survivors": float(h_res["n_ratio"][m].mean()),
+            "mean_matches": float(h_res["n_matches"][m].mean()),
+            "outlier_fraction_of_ratio_survivors": float(1.0 - (h_res["f_inliers"][m] / h_res["n_ratio"][m]).mean()),
+            "mean_f_ransac_iterations": float(h_res["f_iters"][m].mean()),
+            "mean_pnp_iterations": float(h_res["pnp_iters"][m].mean()),
+            "pose_success_rate": float(h_res["pnp_success"].mean()),
+        }
+        t_err = [float(np.linalg.norm(h_res["tvec"][b] - hin[b // Bc][3][(b % Bc) // F][b % F][1]))
+                 for b in range(len(h_res)) if h_res["pnp_success"][b]]
+        hard["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
+        del hf, hd, hin
 
     if rank == 0:
         n_kp = float(res["n_keypoints"].mean())
@@ -230,18 +299,15 @@ def main():
             roof.update(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak)
         # HBM bytes per launch from the PMC passes kept under profiles/ (rocprofv3 cannot run inside this
         # process): used only when they were taken at this launch size; null where the counter is uncalibrated
-        measured = {}
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("frames_per_launch") == Bc:
-                measured = {k: v.get("bytes") for k, v in tj["stages"].items()}
-                busy = {k: v.get("valu_busy") for k, v in tj["stages"].items()}
-                if busy.get(dominant) is not None:
-                    # measured vector-ALU occupancy of the dominant kernel (SQ_ACTIVE_INST_VALU pass kept under
-                    # profiles/): the image kernels are instruction-bound long before they are HBM-bound
-                    roof["valu_busy"] = busy[dominant]
+        stages_pmc, traffic_source = committed_traffic(Bc)
+        measured = {k: v.get("bytes") for k, v in stages_pmc.items()}
+        busy = {k: v.get("valu_busy") for k, v in stages_pmc.items()}
+        if busy.get(dominant) is not None:
+            # measured vector-ALU occupancy of the dominant kernel (SQ_ACTIVE_INST_VALU pass kept under
+            # profiles/): the image kernels are instruction-bound long before they are HBM-bound
+            roof["valu_busy"] = busy[dominant]
         roof["traffic"] = measured.get(dominant)
+        roof["traffic_source"] = traffic_source
         stage_roof = {}
         for k, (bound, amount, peak, unit) in work.items():
             if acc.get(k, 0.0) > 1e-4 and amount > 0:
@@ -260,7 +326,7 @@ def main():
             "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
                                    ("orb8level" if levels else "fast1level"),
                        "detector": args.detector, "matcher": args.matcher, "pyramid_levels": levels or 1,
-                       "streams_per_gpu": S * NC, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
+                       "streams_per_gpu": S * NC, "distinct_streams": True, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
                        "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,
                        "parallelism": "independent streams, one process per GPU, no collective"},
@@ -271,9 +337,13 @@ def main():
             "pose_success_rate": float(res["pnp_success"].mean()),
         }
         # accuracy of the last step's poses against the rendered camera motion (T_prev_from_curr, mm)
-        t_err = [float(np.linalg.norm(res["tvec"][b] - truth[b % F][1])) for b in range(len(res)) if res["pnp_success"][b]]
+        t_err = [float(np.linalg.norm(res["tvec"][b] - truths[b // Bc][(b % Bc) // F][b % F][1]))
+                 for b in range(len(res)) if res["pnp_success"][b]]
         out["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
-        out["ground_truth_step_mm"] = float(np.linalg.norm(truth[1][1]))
+        out["ground_truth_step_mm"] = float(np.linalg.norm(truth[0][1][1]))
+        out["f_ransac_iterations_mean"] = float(res["f_iters"][res["n_ratio"] > 0].mean())
+        if hard is not None:
+            out["hard_scene"] = hard
         if world == 1 and args.cpu_frames > 0:
             cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             if cpu_all is not None:
@@ -284,6 +354,15 @@ def main():
             out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": f"{args.cpu_frames} HD720 frames of the same stream and detector, "
                                              "oracle C pipeline, 1 thread"}
+            if args.cpu_fast:
+                # the other detector for the record: the bench's default is the 8-level detector, the reference node
+                # runs the one-level FAST sequence (and vice versa with --detector fast)
+                other = 0 if levels else 8
+                n_other = max(32, args.cpu_frames // (1 if other == 0 else 2))
+                out["cpu_baseline_other_detector"] = {
+                    "value": cpu_baseline(cam, frames_h[:F], depth_h[:F], n_other, args.features, other),
+                    "unit": "frames/s", "cores": 1, "kind": "port", "detector": "orb" if other else "fast",
+                    "sample": f"{n_other} HD720 frames of the same stream, oracle C pipeline, 1 thread"}
         print(json.dumps(out))
     for c in ctxs:
         c.close()

@@ -13,7 +13,8 @@ import dataclasses
 
 import numpy as np
 
-__all__ = ["Camera", "Scene", "make_sequence", "make_stereo_sequence", "CONFIG_CAMERAS"]
+__all__ = ["Camera", "Scene", "make_sequence", "make_stereo_sequence", "make_streams", "pingpong",
+           "make_pingpong_batch", "CONFIG_CAMERAS"]
 
 
 @dataclasses.dataclass(frozen=True)
@@ -132,18 +133,46 @@ def _rot(rx, ry, rz):
     return Rz @ Ry @ Rx
 
 
+def _movers(scene: Scene, cam: Camera, n: int, seed: int):
+    """n textured rectangles that slide over the image on their own (objects moving independently of the
+    camera): per mover its texture patch, start position, velocity in px per frame and depth in mm."""
+    rng = np.random.default_rng(seed + 104729)
+    th, tw = scene.tex.shape
+    out = []
+    for _ in range(n):
+        w = int(rng.integers(cam.width // 10, cam.width // 4))
+        h = int(rng.integers(cam.height // 8, cam.height // 3))
+        ty, tx = int(rng.integers(0, th - h)), int(rng.integers(0, tw - w))
+        pos = np.array([rng.uniform(0, cam.width - w), rng.uniform(0, cam.height - h)])
+        ang = rng.uniform(0, 2 * np.pi)
+        vel = rng.uniform(4.0, 14.0) * np.array([np.cos(ang), np.sin(ang)])
+        out.append((scene.tex[ty:ty + h, tx:tx + w], pos, vel, float(rng.uniform(1200.0, 2600.0))))
+    return out
+
+
 def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
-                  noise_sigma: float = 2.0, scene: Scene | None = None, baseline_mm: float = 0.0):
+                  noise_sigma: float = 2.0, scene: Scene | None = None, baseline_mm: float = 0.0,
+                  movers: int = 0):
     """Return dict with 'frames' (n,H,W,C uint8 BGR[A] or n,H,W gray when channels==1),
-    'depth' (n,H,W float32 mm), 'poses' (list of (R, c)) and 'camera'."""
+    'depth' (n,H,W float32 mm), 'poses' (list of (R, c)) and 'camera'.  movers > 0 pastes that many
+    independently moving textured rectangles over the rendered scene (their key points match from frame to
+    frame but violate the camera's epipolar geometry: outliers for the RANSAC stages)."""
     scene = scene or Scene(seed)
     rng = np.random.default_rng(seed + 7919)
+    sprites = _movers(scene, cam, movers, seed) if movers > 0 else []
     frames, depths, poses = [], [], []
     for k in range(n_frames):
         R = _rot(np.deg2rad(0.10 * k), np.deg2rad(0.25 * k), np.deg2rad(0.12 * k))
         # baseline_mm moves the camera centre along its own x axis (the right camera of a stereo rig)
         c = np.array([14.0 * k, 4.0 * k, 30.0 * k]) + R.T @ np.array([baseline_mm, 0.0, 0.0])
         gray, depth = scene.render(cam, R, c)
+        for tex, pos, vel, z in sprites:
+            x0, y0 = (int(round(v)) for v in pos + k * vel)
+            xa, ya = max(x0, 0), max(y0, 0)
+            xb, yb = min(x0 + tex.shape[1], cam.width), min(y0 + tex.shape[0], cam.height)
+            if xa < xb and ya < yb:
+                gray[ya:yb, xa:xb] = tex[ya - y0:yb - y0, xa - x0:xb - x0]
+                depth[ya:yb, xa:xb] = z
         gray = gray + rng.normal(0.0, noise_sigma, gray.shape).astype(np.float32)
         g8 = np.clip(np.rint(gray), 0, 255).astype(np.uint8)
         if channels == 1:
@@ -161,6 +190,51 @@ def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
         poses.append((R, c))
     return {"frames": np.stack(frames), "depth": np.stack(depths), "poses": poses,
             "camera": cam}
+
+
+def _stream_job(job):
+    cam, n_frames, seed, channels, relief, movers = job
+    seq = make_sequence(cam, n_frames, seed, channels, scene=Scene(seed, relief=relief), movers=movers)
+    return seq["frames"], seq["depth"], seq["poses"]
+
+
+def make_streams(cam: Camera, n_streams: int, n_frames: int, seed: int, channels: int = 4, relief: float = 1.0,
+                 movers: int = 0, workers: int = 1):
+    """n_streams independent sequences (stream s: scene and noise of seed + s), rendered by `workers` processes.
+    Returns a list of dicts like make_sequence's.  The workers are fresh interpreters (spawn), so this may be
+    called from a process that already uses the GPU."""
+    jobs = [(cam, n_frames, seed + s, channels, relief, movers) for s in range(n_streams)]
+    if workers > 1 and n_streams > 1:
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        with cf.ProcessPoolExecutor(max_workers=min(workers, n_streams), mp_context=mp.get_context("spawn")) as ex:
+            res = list(ex.map(_stream_job, jobs))
+    else:
+        res = [_stream_job(j) for j in jobs]
+    return [{"frames": f, "depth": d, "poses": p, "camera": cam} for f, d, p in res]
+
+
+def pingpong(n):
+    """0, 1, ..., n-1, n-2, ..., 1: every consecutive pair (cyclically) is one camera step apart."""
+    return list(range(n)) + list(range(n - 2, 0, -1))
+
+
+def make_pingpong_batch(cam: Camera, n_streams: int, frames_per_stream: int, seed: int, channels: int = 4,
+                        relief: float = 1.0, movers: int = 0, workers: int = 1):
+    """One launch of the batched pipeline: n_streams independent streams (seed + s), each walking forth and
+    back over frames_per_stream / 2 + 1 rendered frames so that the launch can be repeated without a break in
+    any stream.  Returns frames (S*F, H, W[, C]) and depth (S*F, H, W) in batch order (stream-major), and per
+    stream the ground-truth T_prev_from_curr of each of its F frames."""
+    assert frames_per_stream % 2 == 0
+    n_distinct = frames_per_stream // 2 + 1
+    order = pingpong(n_distinct)
+    assert len(order) == frames_per_stream
+    seqs = make_streams(cam, n_streams, n_distinct, seed, channels, relief, movers, workers)
+    frames = np.concatenate([q["frames"][order] for q in seqs])
+    depth = np.concatenate([q["depth"][order] for q in seqs])
+    truth = [[relative_pose(q["poses"][order[k - 1]], q["poses"][order[k]]) for k in range(frames_per_stream)]
+             for q in seqs]
+    return frames, depth, truth
 
 
 def make_stereo_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4, baseline_mm: float = 120.0):
