@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--render-workers", type=int, default=16, help="processes rendering the synthetic streams")
     ap.add_argument("--hard-scene", type=int, default=1,
                     help="also run the same launch on streams with independently moving objects (0 = skip)")
+    ap.add_argument("--flat-scene", type=int, default=1,
+                    help="also run the same launch on streams that look at a flat wall (0 = skip)")
     ap.add_argument("--cpu-fast", type=int, default=1,
                     help="also time the CPU baseline of the other detector (the one-level FAST sequence the "
                          "reference node runs) for the record (0 = skip)")
@@ -263,6 +265,28 @@ def main():
         hard["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
         del hf, hd, hin
 
+    # and on a flat wall (no depth relief at all): every PnP inlier set is planar, so the pose refinement starts from
+    # a homography instead of the DLT
+    flat = None
+    if args.flat_scene:
+        fin = [build_inputs(S, F, seed=72000 + 1000 * rank + S * k, workers=render_workers, relief=0.0)
+               for k in range(NC)]
+        ff = [torch.from_numpy(i[1]).cuda() for i in fin]
+        fd_ = [torch.from_numpy(i[2]).cuda() for i in fin]
+        for c in ctxs:
+            c.batch_reset()
+        steps_f = max(3, args.steps // 2)
+        f_fps, f_dt, f_res, f_acc = measure(ff, fd_, steps_f, max(2, args.warmup), reps=3)
+        flat = {"value": f_fps, "unit": "frames/s", "steps": steps_f, "ms_per_step": 1e3 * f_dt / steps_f,
+                "scene": "flat wall (relief 0), own texture per stream",
+                "stage_ms_per_launch": {k: round(v, 4) for k, v in f_acc.items()},
+                "mean_matches": float(f_res["n_matches"].mean()),
+                "pose_success_rate": float(f_res["pnp_success"].mean())}
+        t_err = [float(np.linalg.norm(f_res["tvec"][b] - fin[b // Bc][3][(b % Bc) // F][b % F][1]))
+                 for b in range(len(f_res)) if f_res["pnp_success"][b]]
+        flat["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
+        del ff, fd_, fin
+
     if rank == 0:
         n_kp = float(res["n_keypoints"].mean())
         # Algorithmic work of one launch (= the whole batch of Bc frames of one context), per stage.
@@ -344,6 +368,8 @@ def main():
         out["f_ransac_iterations_mean"] = float(res["f_iters"][res["n_ratio"] > 0].mean())
         if hard is not None:
             out["hard_scene"] = hard
+        if flat is not None:
+            out["flat_scene"] = flat
         if world == 1 and args.cpu_frames > 0:
             cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             if cpu_all is not None:

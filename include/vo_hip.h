@@ -303,9 +303,11 @@ int vo_match_features_ex(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev
  * 2^64-1, squared reprojection error <= threshold^2, adaptive iteration count,
  * then solvePnP(SOLVEPNP_ITERATIVE) on the inliers.
  * obj: n x 3 float32, img: n x 2 float32; rvec, tvec: 3 doubles each;
- * inliers: up to n ascending indices.  *success is 0 when no hypothesis has
- * more than 4 inliers, when n < 5 (OpenCV would use P3P for n == 4), or when
- * the inlier set cannot seed the iterative solver (fewer than 6 / planar).
+ * inliers: up to n ascending indices.  The refinement starts from a homography
+ * when the inliers are planar (a wall, the floor) and from the DLT otherwise;
+ * five non-planar inliers keep the pose of their minimal sample, as in OpenCV.
+ * *success is 0 when no hypothesis has more than 4 inliers or when n < 5
+ * (OpenCV would use P3P for n == 4).
  * reference src/frame_processor.cpp:176-196 */
 int vo_solve_pnp_ransac(vo_ctx *ctx, const float *obj, const float *img, int n,
                         double fx, double fy, double cx, double cy, int iters,

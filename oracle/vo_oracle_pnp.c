@@ -644,14 +644,237 @@ static void project_residuals(const double *obj, const double *img, int n, doubl
     }
 }
 
+/* ------------------------------------------------ homography (planar init) */
+
+/* general n x n solve by Gaussian elimination with partial pivoting (n <= 8);
+ * returns 0 when singular */
+static int solve_gauss_n(const double *Ain, const double *bin, int n, double *x)
+{
+    double A[64], b[8];
+    memcpy(A, Ain, sizeof(double) * (size_t)(n * n));
+    memcpy(b, bin, sizeof(double) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
+        if (A[piv * n + k] == 0) return 0;
+        if (piv != k) {
+            for (int j = 0; j < n; j++) { double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < n; i++) {
+            double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double s = b[k];
+        for (int j = k + 1; j < n; j++) s -= A[k * n + j] * x[j];
+        x[k] = s / A[k * n + k];
+    }
+    return 1;
+}
+
+/* projection residuals of the 8-parameter homography (h[8] = 1) and the
+ * accumulated normal equations; [OCV-recall] HomographyRefineCallback */
+static double homography_normal_eq(const float *M, const float *m, int n, const double *h, double *JtJ, double *Jtr)
+{
+    double S = 0;
+    if (JtJ) { memset(JtJ, 0, sizeof(double) * 64); memset(Jtr, 0, sizeof(double) * 8); }
+    for (int i = 0; i < n; i++) {
+        double Mx = M[2 * i], My = M[2 * i + 1];
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        double e0 = xi - m[2 * i], e1 = yi - m[2 * i + 1];
+        S += e0 * e0 + e1 * e1;
+        if (JtJ) {
+            double j0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            double j1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            for (int a = 0; a < 8; a++) {
+                Jtr[a] += j0[a] * e0 + j1[a] * e1;
+                for (int b = 0; b < 8; b++) JtJ[a * 8 + b] += j0[a] * j0[b] + j1[a] * j1[b];
+            }
+        }
+    }
+    return S;
+}
+
+/* [OCV-recall] cv::findHomography(M, m, method = 0) on float32 points: the
+ * normalised DLT of HomographyEstimatorCallback::runKernel (translation to the
+ * centroid, per-axis scale count / sum |d|, 9x9 normal matrix, eigenvector of
+ * the smallest eigenvalue, H / H[8]) followed, for more than four points, by
+ * the Levenberg-Marquardt polish of LMSolver (10 iterations, eps FLT_EPSILON;
+ * its 8x8 solves are done here by Gaussian elimination instead of DECOMP_EIG).
+ * Returns 0 when the point set is degenerate. */
+static int find_homography_ls(const float *M, const float *m, int n, double *H)
+{
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < n; i++) { cmx += m[2 * i]; cmy += m[2 * i + 1]; cMx += M[2 * i]; cMy += M[2 * i + 1]; }
+    cmx /= n; cmy /= n; cMx /= n; cMy /= n;
+    for (int i = 0; i < n; i++) {
+        smx += fabs(m[2 * i] - cmx); smy += fabs(m[2 * i + 1] - cmy);
+        sMx += fabs(M[2 * i] - cMx); sMy += fabs(M[2 * i + 1] - cMy);
+    }
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
+        return 0;
+    smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
+    double LtL[81] = {0}, W[9], Vt[81];
+    for (int i = 0; i < n; i++) {
+        double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
+        double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
+        double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; j++)
+            for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; j++)
+        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
+    jacobi_eig_desc(LtL, 9, W, Vt);
+    const double *H0 = Vt + 8 * 9;
+    double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    double T[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            T[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            H[i * 3 + j] = T[i * 3] * Hnorm2[j] + T[i * 3 + 1] * Hnorm2[3 + j] + T[i * 3 + 2] * Hnorm2[6 + j];
+    double sc = 1. / H[8];
+    for (int i = 0; i < 9; i++) H[i] *= sc;
+    if (n <= 4) return 1;
+
+    /* [OCV-recall] LMSolver run: damping lambda * diag(J^T J) fixed at the start, gain-ratio update */
+    double x[8], xd[8], A[64], v[8], D[8], Ap[64], d[8];
+    memcpy(x, H, sizeof(x));
+    double S = homography_normal_eq(M, m, n, x, A, v);
+    for (int i = 0; i < 8; i++) D[i] = A[i * 8 + i];
+    const double Rlo = 0.25, Rhi = 0.75, epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+    double lambda = 1, lc = 0.75;
+    double rinf = 0;
+    for (int iter = 0;;) {
+        memcpy(Ap, A, sizeof(Ap));
+        for (int i = 0; i < 8; i++) Ap[i * 8 + i] += lambda * D[i];
+        if (!solve_gauss_n(Ap, v, 8, d)) memset(d, 0, sizeof(d));
+        for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
+        double Sd = homography_normal_eq(M, m, n, xd, 0, 0);
+        double dS = 0, t = 0;
+        for (int i = 0; i < 8; i++) {
+            double td = 2 * v[i];
+            for (int j = 0; j < 8; j++) td -= A[i * 8 + j] * d[j];
+            dS += d[i] * td;
+            t += d[i] * v[i];
+        }
+        double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (Rr > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (Rr < Rlo) {
+            double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+            if (lambda == 0) {
+                /* 1 / largest diagonal entry of A^-1 */
+                double maxval = DBL_EPSILON;
+                for (int c = 0; c < 8; c++) {
+                    double e[8] = {0}, col[8];
+                    e[c] = 1;
+                    if (solve_gauss_n(A, e, 8, col) && fabs(col[c]) > maxval) maxval = fabs(col[c]);
+                }
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            memcpy(x, xd, sizeof(x));
+            S = homography_normal_eq(M, m, n, x, A, v);
+        }
+        /* |r|_inf of the current residual vector */
+        rinf = 0;
+        for (int i = 0; i < n; i++) {
+            double Mx = M[2 * i], My = M[2 * i + 1];
+            double ww = x[6] * Mx + x[7] * My + 1.;
+            ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+            double e0 = fabs((x[0] * Mx + x[1] * My + x[2]) * ww - m[2 * i]);
+            double e1 = fabs((x[3] * Mx + x[4] * My + x[5]) * ww - m[2 * i + 1]);
+            if (e0 > rinf) rinf = e0;
+            if (e1 > rinf) rinf = e1;
+        }
+        double dinf = 0;
+        for (int i = 0; i < 8; i++) if (fabs(d[i]) > dinf) dinf = fabs(d[i]);
+        iter++;
+        if (!(iter < 10 && dinf >= epsx && rinf >= epsf)) break;
+    }
+    memcpy(H, x, sizeof(x));
+    H[8] = 1;
+    return 1;
+}
+
+/* [OCV-recall] the planar branch of cvFindExtrinsicCameraParams2: the object
+ * points are rotated into their own plane (rows of Vt = principal axes, Mc the
+ * centroid), a homography to the normalised image points is fitted and split
+ * into a rotation and a translation.  param receives rvec, tvec. */
+static void planar_pose_init(const double *obj, const double *img, int n, double fx, double fy, double cx,
+                             double cy, const double *Mc, const double *Vt_in, double *param)
+{
+    double Rt[9], T[3];
+    memcpy(Rt, Vt_in, sizeof(Rt));
+    if (Rt[2] * Rt[2] + Rt[5] * Rt[5] < 1e-10) {
+        for (int i = 0; i < 9; i++) Rt[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    double det = Rt[0] * (Rt[4] * Rt[8] - Rt[5] * Rt[7]) - Rt[1] * (Rt[3] * Rt[8] - Rt[5] * Rt[6]) +
+                 Rt[2] * (Rt[3] * Rt[7] - Rt[4] * Rt[6]);
+    if (det < 0)
+        for (int i = 0; i < 9; i++) Rt[i] = -Rt[i];
+    for (int i = 0; i < 3; i++) T[i] = -(Rt[3 * i] * Mc[0] + Rt[3 * i + 1] * Mc[1] + Rt[3 * i + 2] * Mc[2]);
+    float *Mxy = (float *)malloc(sizeof(float) * 2 * (size_t)n), *mn = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        const double *s = obj + 3 * i;
+        /* cv::findHomography converts its inputs to float32 */
+        Mxy[2 * i] = (float)(Rt[0] * s[0] + Rt[1] * s[1] + Rt[2] * s[2] + T[0]);
+        Mxy[2 * i + 1] = (float)(Rt[3] * s[0] + Rt[4] * s[1] + Rt[5] * s[2] + T[1]);
+        mn[2 * i] = (float)((img[2 * i] - cx) / fx);
+        mn[2 * i + 1] = (float)((img[2 * i + 1] - cy) / fy);
+    }
+    double h[9], R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    int okH = find_homography_ls(Mxy, mn, n, h);
+    for (int i = 0; i < 9 && okH; i++) if (!isfinite(h[i])) okH = 0;
+    if (okH) {
+        double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+        double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+        double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+        double s3 = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+        double a[3] = {h[0] * s1, h[3] * s1, h[6] * s1}, b[3] = {h[1] * s2, h[4] * s2, h[7] * s2};
+        double tt[3] = {h[2] * s3, h[5] * s3, h[8] * s3};
+        double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        double Hm[9] = {a[0], b[0], c[0], a[1], b[1], c[1], a[2], b[2], c[2]}, Hr[9], rv[3];
+        /* Rodrigues there and back: the nearest rotation */
+        polar_rotation3(Hm, Hr);
+        ora_rodrigues_mat2vec(Hr, rv);
+        rodrigues_v2m(rv, Hr, 0);
+        for (int i = 0; i < 3; i++) t[i] = Hr[3 * i] * T[0] + Hr[3 * i + 1] * T[1] + Hr[3 * i + 2] * T[2] + tt[i];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R[i * 3 + j] = Hr[i * 3] * Rt[j] + Hr[i * 3 + 1] * Rt[3 + j] + Hr[i * 3 + 2] * Rt[6 + j];
+    }
+    ora_rodrigues_mat2vec(R, param);
+    for (int i = 0; i < 3; i++) param[3 + i] = t[i];
+    free(Mxy); free(mn);
+}
+
 /* [OCV-recall] cvFindExtrinsicCameraParams2 without extrinsic guess:
- * DLT initialisation (non-planar, >= 6 points) + CvLevMarq (<= 20 iterations,
- * eps FLT_EPSILON).  obj n x 3, img n x 2 pixels. Returns 0 when the DLT
- * preconditions fail (planar or fewer than 6 points -- not restated). */
+ * initialisation from a homography when the object points are (nearly) planar
+ * (>= 4 points), else by DLT (>= 6 points; OpenCV throws below that and the
+ * function returns 0), then CvLevMarq (<= 20 iterations, eps FLT_EPSILON).
+ * obj n x 3, img n x 2 pixels. */
 int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, double fy, double cx,
                       double cy, double *rvec, double *tvec)
 {
-    if (n < 6) return 0;
+    if (n < 4) return 0;
     /* planarity test on the object points */
     double Mc[3] = {0, 0, 0}, MM[9] = {0}, W[3], Vt[9];
     for (int i = 0; i < n; i++)
@@ -663,8 +886,11 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
             for (int b = 0; b < 3; b++) MM[a * 3 + b] += d[a] * d[b];
     }
     jacobi_eig_desc(MM, 3, W, Vt);
-    if (W[2] / W[1] < 1e-3) return 0;
-
+    double param[6], prev[6];
+    if (W[2] / W[1] < 1e-3) {
+        planar_pose_init(obj, img, n, fx, fy, cx, cy, Mc, Vt, param);
+    } else {
+    if (n < 6) return 0; /* "DLT algorithm needs at least 6 points" */
     /* DLT on normalised image points */
     double LL[144] = {0}, LW[12], LV[144];
     for (int i = 0; i < n; i++) {
@@ -700,9 +926,9 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
     double nR = 0;
     for (int i = 0; i < 9; i++) nR += R[i] * R[i];
     nR = sqrt(nR);
-    double param[6], prev[6];
     ora_rodrigues_mat2vec(R, param);
     for (int i = 0; i < 3; i++) param[3 + i] = tt[i] * nR / sc;
+    }
 
     /* CvLevMarq */
     const int max_iter = 20;
@@ -869,14 +1095,19 @@ int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx, d
                 ii[2 * k] = img[2 * i]; ii[2 * k + 1] = img[2 * i + 1];
                 k++;
             }
-        if (ora_pnp_iterative(io, ii, k, fx, fy, cx, cy, rvec, tvec)) {
+        int refined = ora_pnp_iterative(io, ii, k, fx, fy, cx, cy, rvec, tvec);
+        if (!refined) {
+            /* five non-planar inliers: the DLT initialisation throws "needs at least 6 points"; OpenCV >= 4.5.2
+             * catches exactly that case and keeps the pose of the minimal sample set.  Anything else fails. */
+            memcpy(rvec, best_r, sizeof(best_r));
+            memcpy(tvec, best_t, sizeof(best_t));
+            refined = k == 5;
+        }
+        if (refined) {
             ok = 1;
             k = 0;
             for (int i = 0; i < n; i++) if (mask[i]) inliers[k++] = i;
             *n_inliers = k;
-        } else {
-            memcpy(rvec, best_r, sizeof(best_r));
-            memcpy(tvec, best_t, sizeof(best_t));
         }
         free(io); free(ii);
     }

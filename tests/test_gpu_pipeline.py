@@ -48,6 +48,89 @@ def test_solve_pnp_ransac(ctx, oracle, n, outliers, noise):
             assert np.abs(rv_g - rv).max() < 5e-3 and np.abs(t_g - t).max() < 25.0  # near ground truth
 
 
+def _planar_points(rng, n, cam, plane, outlier_frac, noise, jitter=0.0):
+    """Points on a plane z = plane(x, y) (+- jitter mm: measured depth is never exactly flat) seen from a known pose."""
+    x, y = rng.uniform(-1500, 1500, n), rng.uniform(-900, 900, n)
+    X = np.stack([x, y, plane(x, y) + rng.normal(0, 1.0, n) * jitter], 1)
+    rv = np.array([0.012, -0.02, 0.015])
+    t = np.array([30.0, -12.0, 55.0])
+    th = np.linalg.norm(rv)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    Y = X @ R.T + t
+    uv = np.stack([Y[:, 0] / Y[:, 2] * cam.fx + cam.cx, Y[:, 1] / Y[:, 2] * cam.fy + cam.cy], 1)
+    uv += rng.normal(0, noise, uv.shape)
+    bad = rng.random(n) < outlier_frac
+    uv[bad] = rng.uniform([0, 0], [cam.width, cam.height], (int(bad.sum()), 2))
+    return X.astype(np.float32), uv.astype(np.float32), rv, t
+
+
+PLANES = {
+    "wall": lambda x, y: 3000 + 0.5 * x - 0.2 * y,
+    "floor": lambda x, y: 2500 + 1.5 * y,
+    "facing": lambda x, y: 3500 + 0 * x,
+}
+
+
+@pytest.mark.parametrize("plane,n,outliers,noise,jitter", [
+    ("wall", 400, 0.3, 0.5, 0.0), ("wall", 50, 0.0, 0.2, 0.0), ("wall", 7, 0.0, 0.1, 0.0),
+    ("floor", 1500, 0.4, 1.0, 0.0), ("floor", 6, 0.0, 0.1, 0.0),
+    ("facing", 300, 0.2, 0.5, 0.05), ("facing", 40, 0.0, 0.3, 0.3),
+])
+def test_solve_pnp_ransac_planar_points(ctx, oracle, plane, n, outliers, noise, jitter):
+    """A planar inlier set (a wall, the floor): solvePnP(ITERATIVE) starts from a homography instead of the DLT
+    (cvFindExtrinsicCameraParams2's planar branch, W[2]/W[1] < 1e-3) and succeeds."""
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    rng = np.random.default_rng(n)
+    X, uv, rv, t = _planar_points(rng, n, cam, PLANES[plane], outliers, noise, jitter)
+    ok_r, rv_r, t_r, inl_r = oracle.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy)
+    ok, rv_g, t_g, inl = ctx.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy)
+    assert ok_r and ok
+    assert np.array_equal(inl, inl_r) and len(inl) >= 0.5 * n
+    _assert_pose_close(rv_g, t_g, rv_r, t_r)
+    if n >= 40:
+        assert np.abs(rv_g - rv).max() < 5e-3 and np.abs(t_g - t).max() < 25.0  # near ground truth
+
+
+def test_solve_pnp_ransac_five_inliers_keep_minimal_sample_pose(ctx, oracle):
+    """Five non-planar inliers cannot seed the DLT (six needed); OpenCV keeps the pose of the minimal sample and
+    reports success."""
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    rng = np.random.default_rng(99)
+    X, uv, rv, t = _scene_points(rng, 5, cam, 0.0, 0.0)
+    Xo = np.concatenate([X, rng.uniform([-2000, -1200, 2000], [2000, 1200, 6000], (6, 3)).astype(np.float32)])
+    uvo = np.concatenate([uv, rng.uniform([0, 0], [cam.width, cam.height], (6, 2)).astype(np.float32)])
+    ok_r, rv_r, t_r, inl_r = oracle.solve_pnp_ransac(Xo, uvo, cam.fx, cam.fy, cam.cx, cam.cy)
+    ok, rv_g, t_g, inl = ctx.solve_pnp_ransac(Xo, uvo, cam.fx, cam.fy, cam.cx, cam.cy)
+    assert ok == ok_r and np.array_equal(inl, inl_r)
+    if ok_r and len(inl_r) == 5:
+        _assert_pose_close(rv_g, t_g, rv_r, t_r)
+
+
+def test_batch_pipeline_flat_wall(ctx, oracle):
+    """A camera facing a flat wall (relief 0): every frame's PnP inlier set is planar, the pose comes out through
+    the homography initialisation, bit-exact match lists and poses within tolerance of the oracle."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    F = 4
+    for levels in (0, 8):
+        seq = synth.make_sequence(cam, F, seed=31, channels=4, scene=synth.Scene(31, relief=0.0))
+        ref = OracleStream(K, 1000, 20, orb_levels=levels, feature_cap=ctx.max_features)
+        ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=F, max_features=1000, camera=K,
+                            orb_levels=levels)
+        ctx.batch_submit(seq["frames"], seq["depth"])
+        res = ctx.batch_wait()
+        for f in range(F):
+            r = ref.process(seq["frames"][f], seq["depth"][f])
+            _compare_frame(ctx, res, f, r, pose=True)
+            if f:
+                assert r["pnp_success"] and res["pnp_success"][f]
+                _, t_true = synth.relative_pose(seq["poses"][f - 1], seq["poses"][f])
+                assert np.linalg.norm(res["tvec"][f] - t_true) < 15.0  # mm, on a 33 mm step (sideways motion and rotation trade off on a plane)
+
+
 def _compare_frame(ctx, res, b, ref, pose):
     k, d = ctx.batch_features(b)
     assert np.array_equal(k, ref["kps"]) and np.array_equal(d, ref["desc"])

@@ -23,14 +23,19 @@ def _rpy(R):
     return np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], sy), np.arctan2(R[1, 0], R[0, 0])
 
 
-def test_replay_trajectory_against_ground_truth(oracle):
+# relief 2: strong depth relief, the PnP refinement starts from the DLT; relief 0: a flat wall, every inlier set
+# is planar and the refinement starts from a homography (sideways translation and rotation trade off against
+# each other on a plane, so the drift bound is wider there).  A shallow but not planar scene (relief 1: depth
+# 3.5 m +- 1.1 m, W[2]/W[1] = 0.08) is left out on purpose: OpenCV's unnormalised DLT then often returns the
+# mirrored solution with every point behind the camera, the Levenberg-Marquardt refinement stays in that
+# minimum, and so do this library and its oracle (they agree with each other there, not with the ground truth).
+@pytest.mark.parametrize("relief,drift_mm,drift_rel,rot_tol", [(2.0, 5.0, 0.05, 5e-3), (0.0, 12.0, 0.12, 1.2e-2)])
+def test_replay_trajectory_against_ground_truth(oracle, relief, drift_mm, drift_rel, rot_tol):
     from oracle.pipeline import OracleStream
     assert os.path.exists(BIN), "build tools/vo_replay with __graft_entry__.build()"
     cam = synth.CONFIG_CAMERAS["vga"]
     n = 10
-    # a scene with strong depth relief: on a nearly planar point set the DLT that initialises
-    # solvePnP(SOLVEPNP_ITERATIVE) is ambiguous and the pose can land in the mirrored minimum
-    seq = synth.make_sequence(cam, n, seed=909, channels=4, scene=synth.Scene(909, relief=2.0))
+    seq = synth.make_sequence(cam, n, seed=909, channels=4, scene=synth.Scene(909, relief=relief))
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
         f.write(np.ascontiguousarray(seq["frames"]).tobytes())
         f.write(np.ascontiguousarray(seq["depth"], np.float32).tobytes())
@@ -67,6 +72,7 @@ def test_replay_trajectory_against_ground_truth(oracle):
         # ground truth: T_0_from_i from the rendered camera poses
         Rg, tg = synth.relative_pose(seq["poses"][0], seq["poses"][i])
         travelled = np.linalg.norm(tg)
-        assert np.linalg.norm(T_got[:, 3] - tg) < 5.0 + 0.05 * travelled       # millimetres: < 5 % drift
-        assert np.abs(T_got[:, :3] - Rg).max() < 5e-3
+        assert np.linalg.norm(T_got[:, 3] - tg) < drift_mm + drift_rel * travelled   # millimetres
+        assert np.abs(T_got[:, :3] - Rg).max() < rot_tol
+        assert i == 0 or int(tok[tok.index("pnp") + 1]) == 1, "every frame after the first yields a pose"
     assert travelled > 250  # the camera really moved (mm)

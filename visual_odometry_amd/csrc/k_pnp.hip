@@ -28,7 +28,7 @@ constexpr int PR_WAVES = PR_THREADS / kWave;
 constexpr int PR_GROUP = 16;                      // lanes per hypothesis
 constexpr int PR_CHUNK = PR_THREADS / PR_GROUP;   // hypotheses per round
 constexpr int PR_WIN = PR_CHUNK * 5 + 96;         // RNG words examined per round
-constexpr int PR_NRED = 43;                       // 36 JtJ + 6 JtErr + |err|^2
+constexpr int PR_NRED = 45;                       // 36 JtJ + 6 JtErr + |err|^2 (pose); 36 + 8 + 1 (homography)
 
 // ---------------------------------------------------------------------
 // small dense algebra, register resident (all indices static after unrolling)
@@ -682,6 +682,14 @@ struct PrShared {
     long long pos;
     int scan_base;
     int lm_ok;
+    // planar initialisation (homography) of the refinement
+    int init_mode;        // 0 DLT, 1 homography (planar inliers), 2 five non-planar inliers: keep the RANSAC pose
+    int h_flag;           // block-uniform decisions of the homography polish
+    double pl[12];        // rotation into the plane (row-major 3x3) and translation
+    double hn[8];         // centroids and scales of the normalised DLT: cMx cMy cmx cmy sMx sMy smx smy
+    double hA[64], hv[8], hD[8], hx[8], hxd[8], hd[8];
+    double hS, hlambda, hlc, hrinf;
+    double wmax[PR_WAVES];
 };
 
 __device__ __forceinline__ int draw_subset5(const uint16_t *r, int o, int (&idx)[5])
@@ -743,6 +751,344 @@ __device__ void block_reduce(PrShared &S, double (&v)[NV])
         double x = 0;
         for (int w = 0; w < PR_WAVES; w++) x += S.red[w][threadIdx.x];
         S.sums[threadIdx.x] = x;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------
+// planar inlier sets: the homography initialisation of
+// cvFindExtrinsicCameraParams2 (cv::solvePnP, SOLVEPNP_ITERATIVE)
+// ---------------------------------------------------------------------
+
+// cyclic Jacobi eigen-decomposition of a symmetric 9x9 matrix; returns the unit
+// eigenvector of the smallest eigenvalue.  One lane, arrays in private memory:
+// only planar frames come here.
+__device__ __noinline__ void eig9_smallest(const double *Ain, double *vec)
+{
+    constexpr int N = 9;
+    double A[N * N], V[N * N];
+    for (int i = 0; i < N * N; i++) { A[i] = Ain[i]; V[i] = (i % (N + 1) == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+                if (i != j) off += A[i * N + j] * A[i * N + j];
+                else diag += A[i * N + j] * A[i * N + j];
+            }
+        if (off <= 1e-30 * diag || off == 0) break;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q * N + q] - A[p * N + p]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < N; k++) {
+                    const double akp = A[k * N + p], akq = A[k * N + q];
+                    A[k * N + p] = c * akp - sn * akq;
+                    A[k * N + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < N; k++) {
+                    const double apk = A[p * N + k], aqk = A[q * N + k];
+                    A[p * N + k] = c * apk - sn * aqk;
+                    A[q * N + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < N; k++) {
+                    const double vkp = V[k * N + p], vkq = V[k * N + q];
+                    V[k * N + p] = c * vkp - sn * vkq;
+                    V[k * N + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    // the last of the eigenvalues in descending order (ties: the one a stable exchange sort leaves last)
+    int order[N];
+    for (int i = 0; i < N; i++) order[i] = i;
+    for (int i = 0; i < N; i++)
+        for (int j = i + 1; j < N; j++)
+            if (A[order[j] * N + order[j]] > A[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    const int m = order[N - 1];
+    for (int k = 0; k < N; k++) vec[k] = V[k * N + m];
+}
+
+// 8x8 solve, Gaussian elimination with partial pivoting; false when singular
+__device__ __noinline__ bool solve_gauss8(const double *Ain, const double *bin, double *x)
+{
+    constexpr int n = 8;
+    double A[64], b[8];
+    for (int i = 0; i < 64; i++) A[i] = Ain[i];
+    for (int i = 0; i < 8; i++) b[i] = bin[i];
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++)
+            if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
+        if (A[piv * n + k] == 0) return false;
+        if (piv != k) {
+            for (int j = 0; j < n; j++) { const double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < n; i++) {
+            const double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double sm = b[k];
+        for (int j = k + 1; j < n; j++) sm -= A[k * n + j] * x[j];
+        x[k] = sm / A[k * n + k];
+    }
+    return true;
+}
+
+// block-wide maximum of one non-negative value per thread
+__device__ double block_max(PrShared &S, double v)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    if (lane == 0) S.wmax[wave] = v;
+    __syncthreads();
+    double m = 0;
+    for (int w = 0; w < PR_WAVES; w++) m = fmax(m, S.wmax[w]);
+    __syncthreads();
+    return m;
+}
+
+// the inlier's point in its plane and its normalised image point, both rounded
+// to float32 as cv::findHomography does with its inputs
+__device__ __forceinline__ void planar_pair(const PrShared &S, const float *o, const float *im, double fx, double fy,
+                                            double cx, double cy, float *M, float *m)
+{
+    const double s0 = o[0], s1 = o[1], s2 = o[2];
+    M[0] = (float)(S.pl[0] * s0 + S.pl[1] * s1 + S.pl[2] * s2 + S.pl[9]);
+    M[1] = (float)(S.pl[3] * s0 + S.pl[4] * s1 + S.pl[5] * s2 + S.pl[10]);
+    m[0] = (float)(((double)im[0] - cx) / fx);
+    m[1] = (float)(((double)im[1] - cy) / fy);
+}
+
+// Normal equations (upper triangle of J^T J, J^T r), squared error and largest
+// residual of the 8-parameter homography x over the inliers -> S.hA, S.hv,
+// S.hS, S.hrinf (HomographyRefineCallback).  with_j = false: squared error only,
+// returned to every thread.
+__device__ double homography_pass(PrShared &S, const float *obj, const float *img, const uint8_t *msk, int n,
+                                  const double *xs, bool with_j, double fx, double fy, double cx, double cy)
+{
+    double h[8];
+    for (int j = 0; j < 8; j++) h[j] = xs[j];
+    double acc[PR_NRED];
+#pragma unroll
+    for (int j = 0; j < PR_NRED; j++) acc[j] = 0;
+    double rmax = 0;
+    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
+        if (!msk[i]) continue;
+        float Mf[2], mf[2];
+        planar_pair(S, obj + 3 * i, img + 2 * i, fx, fy, cx, cy, Mf, mf);
+        const double Mx = Mf[0], My = Mf[1];
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        const double e0 = xi - (double)mf[0], e1 = yi - (double)mf[1];
+        acc[44] += e0 * e0 + e1 * e1;
+        if (with_j) {
+            rmax = fmax(rmax, fmax(fabs(e0), fabs(e1)));
+            const double j0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+            const double j1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+#pragma unroll
+                for (int bb = a; bb < 8; bb++, q++) acc[q] += j0[a] * j0[bb] + j1[a] * j1[bb];
+                acc[36 + a] += j0[a] * e0 + j1[a] * e1;
+            }
+        }
+    }
+    block_reduce<PR_NRED>(S, acc);
+    const double sse = S.sums[44];
+    if (with_j) {
+        const double rinf = block_max(S, rmax);
+        if (threadIdx.x == 0) {
+            int q = 0;
+            for (int a = 0; a < 8; a++)
+                for (int bb = a; bb < 8; bb++, q++) S.hA[a * 8 + bb] = S.hA[bb * 8 + a] = S.sums[q];
+            for (int a = 0; a < 8; a++) S.hv[a] = S.sums[36 + a];
+            S.hS = sse;
+            S.hrinf = rinf;
+        }
+    }
+    __syncthreads();
+    return sse;
+}
+
+// Pose initialisation from a homography for a planar inlier set; S.pl holds the
+// rotation into the plane and the translation.  Leaves rvec, tvec in S.param.
+// Every thread of the block calls it.
+__device__ __noinline__ void planar_pose_init(PrShared &S, const float *obj, const float *img, const uint8_t *msk, int n,
+                                              int k, double fx, double fy, double cx, double cy)
+{
+    const int tid = threadIdx.x;
+    // --- cv::findHomography, method 0: normalised DLT
+    {
+        double c4[4] = {0, 0, 0, 0};
+        for (int i = tid; i < n; i += PR_THREADS) {
+            if (!msk[i]) continue;
+            float Mf[2], mf[2];
+            planar_pair(S, obj + 3 * i, img + 2 * i, fx, fy, cx, cy, Mf, mf);
+            c4[0] += Mf[0]; c4[1] += Mf[1]; c4[2] += mf[0]; c4[3] += mf[1];
+        }
+        block_reduce<4>(S, c4);
+        if (tid < 4) S.hn[tid] = S.sums[tid] / k;
+        __syncthreads();
+        double s4[4] = {0, 0, 0, 0};
+        for (int i = tid; i < n; i += PR_THREADS) {
+            if (!msk[i]) continue;
+            float Mf[2], mf[2];
+            planar_pair(S, obj + 3 * i, img + 2 * i, fx, fy, cx, cy, Mf, mf);
+            s4[0] += fabs((double)Mf[0] - S.hn[0]); s4[1] += fabs((double)Mf[1] - S.hn[1]);
+            s4[2] += fabs((double)mf[0] - S.hn[2]); s4[3] += fabs((double)mf[1] - S.hn[3]);
+        }
+        block_reduce<4>(S, s4);
+        if (tid == 0) {
+            bool ok = true;
+            for (int j = 0; j < 4; j++) ok = ok && !(fabs(S.sums[j]) < DBL_EPSILON);
+            for (int j = 0; j < 4; j++) S.hn[4 + j] = ok ? k / S.sums[j] : 0.0;
+            S.h_flag = ok ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    bool okH = S.h_flag != 0;
+    if (okH) {
+        double acc[PR_NRED];
+#pragma unroll
+        for (int j = 0; j < PR_NRED; j++) acc[j] = 0;
+        const double cMx = S.hn[0], cMy = S.hn[1], cmx = S.hn[2], cmy = S.hn[3];
+        const double sMx = S.hn[4], sMy = S.hn[5], smx = S.hn[6], smy = S.hn[7];
+        for (int i = tid; i < n; i += PR_THREADS) {
+            if (!msk[i]) continue;
+            float Mf[2], mf[2];
+            planar_pair(S, obj + 3 * i, img + 2 * i, fx, fy, cx, cy, Mf, mf);
+            const double x = ((double)mf[0] - cmx) * smx, y = ((double)mf[1] - cmy) * smy;
+            const double X = ((double)Mf[0] - cMx) * sMx, Y = ((double)Mf[1] - cMy) * sMy;
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 9; a++)
+#pragma unroll
+                for (int bb = a; bb < 9; bb++, q++) acc[q] += Lx[a] * Lx[bb] + Ly[a] * Ly[bb];
+        }
+        block_reduce<PR_NRED>(S, acc);
+        if (tid == 0) {
+            double LtL[81], H0[9], T[9], H[9];
+            int q = 0;
+            for (int a = 0; a < 9; a++)
+                for (int bb = a; bb < 9; bb++, q++) LtL[a * 9 + bb] = LtL[bb * 9 + a] = S.sums[q];
+            eig9_smallest(LtL, H0);
+            const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+            const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    T[i * 3 + j] = invHnorm[i * 3] * H0[j] + invHnorm[i * 3 + 1] * H0[3 + j] + invHnorm[i * 3 + 2] * H0[6 + j];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    H[i * 3 + j] = T[i * 3] * Hnorm2[j] + T[i * 3 + 1] * Hnorm2[3 + j] + T[i * 3 + 2] * Hnorm2[6 + j];
+            const double sc = 1. / H[8];
+            for (int j = 0; j < 8; j++) S.hx[j] = H[j] * sc;
+        }
+        __syncthreads();
+        if (k > 4) {
+            // --- the Levenberg-Marquardt polish of LMSolver: 10 iterations, eps FLT_EPSILON
+            homography_pass(S, obj, img, msk, n, S.hx, true, fx, fy, cx, cy);
+            if (tid == 0) {
+                for (int j = 0; j < 8; j++) S.hD[j] = S.hA[j * 8 + j];
+                S.hlambda = 1;
+                S.hlc = 0.75;
+            }
+            __syncthreads();
+            for (int iter = 0;;) {
+                if (tid == 0) {
+                    double Ap[64], d[8];
+                    for (int j = 0; j < 64; j++) Ap[j] = S.hA[j];
+                    for (int j = 0; j < 8; j++) Ap[j * 8 + j] += S.hlambda * S.hD[j];
+                    if (!solve_gauss8(Ap, S.hv, d)) {
+                        for (int j = 0; j < 8; j++) d[j] = 0;
+                    }
+                    for (int j = 0; j < 8; j++) { S.hd[j] = d[j]; S.hxd[j] = S.hx[j] - d[j]; }
+                }
+                __syncthreads();
+                const double Sd = homography_pass(S, obj, img, msk, n, S.hxd, false, fx, fy, cx, cy);
+                if (tid == 0) {
+                    const double Sc = S.hS;
+                    double dS = 0, t = 0;
+                    for (int i = 0; i < 8; i++) {
+                        double td = 2 * S.hv[i];
+                        for (int j = 0; j < 8; j++) td -= S.hA[i * 8 + j] * S.hd[j];
+                        dS += S.hd[i] * td;
+                        t += S.hd[i] * S.hv[i];
+                    }
+                    const double Rr = (Sc - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+                    if (Rr > 0.75) {
+                        S.hlambda *= 0.5;
+                        if (S.hlambda < S.hlc) S.hlambda = 0;
+                    } else if (Rr < 0.25) {
+                        double nu = (Sd - Sc) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+                        nu = nu < 2. ? 2. : (nu > 10. ? 10. : nu);
+                        if (S.hlambda == 0) {
+                            // 1 / largest diagonal entry of A^-1
+                            double maxval = DBL_EPSILON;
+                            for (int c = 0; c < 8; c++) {
+                                double e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, col[8];
+                                e[c] = 1;
+                                if (solve_gauss8(S.hA, e, col) && fabs(col[c]) > maxval) maxval = fabs(col[c]);
+                            }
+                            S.hlambda = S.hlc = 1. / maxval;
+                            nu *= 0.5;
+                        }
+                        S.hlambda *= nu;
+                    }
+                    S.h_flag = Sd < Sc ? 1 : 0;
+                    if (Sd < Sc)
+                        for (int j = 0; j < 8; j++) S.hx[j] = S.hxd[j];
+                }
+                __syncthreads();
+                if (S.h_flag) homography_pass(S, obj, img, msk, n, S.hx, true, fx, fy, cx, cy);
+                double dinf = 0;
+                for (int j = 0; j < 8; j++) dinf = fmax(dinf, fabs(S.hd[j]));
+                iter++;
+                const bool proceed = iter < 10 && dinf >= (double)FLT_EPSILON && S.hrinf >= (double)FLT_EPSILON;
+                __syncthreads();
+                if (!proceed) break;
+            }
+        }
+    }
+    if (tid == 0) {
+        double h[9];
+        for (int j = 0; j < 8; j++) h[j] = S.hx[j];
+        h[8] = 1;
+        for (int j = 0; j < 8 && okH; j++) okH = isfinite(h[j]);
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+        if (okH) {
+            const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+            const double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+            const double s3 = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+            const double a[3] = {h[0] * s1, h[3] * s1, h[6] * s1}, b[3] = {h[1] * s2, h[4] * s2, h[7] * s2};
+            const double tt[3] = {h[2] * s3, h[5] * s3, h[8] * s3};
+            const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double Hm[9] = {a[0], b[0], c[0], a[1], b[1], c[1], a[2], b[2], c[2]};
+            double Hr[9], rv[3];
+            // cv::Rodrigues there and back: the nearest rotation
+            polar_rotation3(Hm, Hr);
+            rodrigues_m2v(Hr, rv);
+            rodrigues_v2m(rv, Hr, nullptr);
+            for (int i = 0; i < 3; i++)
+                t[i] = Hr[3 * i] * S.pl[9] + Hr[3 * i + 1] * S.pl[10] + Hr[3 * i + 2] * S.pl[11] + tt[i];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    R[i * 3 + j] = Hr[i * 3] * S.pl[j] + Hr[i * 3 + 1] * S.pl[3 + j] + Hr[i * 3 + 2] * S.pl[6 + j];
+        }
+        double rv[3];
+        rodrigues_m2v(R, rv);
+        for (int j = 0; j < 3; j++) { S.param[j] = rv[j]; S.param[3 + j] = t[j]; }
     }
     __syncthreads();
 }
@@ -1018,8 +1364,8 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     PNP_STAMP(5);
 
     // ---------------- refinement: solvePnP(SOLVEPNP_ITERATIVE) on inliers ----
-    bool init_ok = k >= 6;
-    if (init_ok) {
+    bool init_ok = true;
+    {
         // planarity test of the object points (cvFindExtrinsicCameraParams2)
         double c3[3] = {0, 0, 0};
         for (int i = tid; i < n; i += PR_THREADS)
@@ -1043,13 +1389,30 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
             double MM[9], W[3], Vt[9];
             for (int j = 0; j < 9; j++) MM[j] = S.sums[j];
             eig3_desc(MM, W, Vt);
-            S.lm_ok = !(W[2] / W[1] < 1e-3);
+            S.lm_ok = 1;
+            if (W[2] / W[1] < 1e-3) {
+                // a planar structure: rotate the points into their plane (rows of Vt = principal axes)
+                S.init_mode = 1;
+                if (Vt[2] * Vt[2] + Vt[5] * Vt[5] < 1e-10) {
+                    for (int j = 0; j < 9; j++) Vt[j] = (j % 4 == 0) ? 1.0 : 0.0;
+                }
+                const double det = Vt[0] * (Vt[4] * Vt[8] - Vt[5] * Vt[7]) - Vt[1] * (Vt[3] * Vt[8] - Vt[5] * Vt[6]) +
+                                   Vt[2] * (Vt[3] * Vt[7] - Vt[4] * Vt[6]);
+                for (int j = 0; j < 9; j++) S.pl[j] = det < 0 ? -Vt[j] : Vt[j];
+                for (int j = 0; j < 3; j++)
+                    S.pl[9 + j] = -(S.pl[3 * j] * Mc[0] + S.pl[3 * j + 1] * Mc[1] + S.pl[3 * j + 2] * Mc[2]);
+            } else {
+                // the DLT needs six points; with five OpenCV (>= 4.5.2) catches the exception of its own solvePnP
+                // call and keeps the pose of the minimal sample
+                S.init_mode = k >= 6 ? 0 : 2;
+            }
         }
         __syncthreads();
-        init_ok = S.lm_ok != 0;
     }
+    const int init_mode = S.init_mode;
     PNP_STAMP(6);
-    if (init_ok) {
+    if (init_mode == 1) planar_pose_init(S, obj, img, msk, n, k, fx, fy, cx, cy);
+    if (init_mode == 0) {
         // DLT: L^T L has the block form [[P, 0, Px], [0, P, Py], [Px, Py, Pxy]]
         // with P = sum m m^T, m = (X, Y, Z, 1); x, y = minus the normalised image point
         double acc[40];
@@ -1073,6 +1436,10 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         }
         block_reduce<40>(S, acc);
         PNP_STAMP(7);
+        // (if the decomposition below breaks down in NaNs no lane owns the smallest singular value: the zero
+        // vector then fails the scale test instead of stale memory seeding the refinement)
+        if (tid < 12) S.null12[tid] = 0;
+        __syncthreads();
         if (wave == 0) {
             // column gl of the symmetric 12 x 12 matrix, then its singular vectors
             const int gl = lane & (PR_GROUP - 1);
@@ -1129,7 +1496,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     }
 
     PNP_STAMP(9);
-    if (init_ok) {
+    if (init_ok && init_mode != 2) {
         // CvLevMarq: <= 20 iterations, epsilon FLT_EPSILON, lambda = 10^lambdaLg10
         const int max_iter = 20;
         const double eps = FLT_EPSILON;
@@ -1239,9 +1606,9 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     __syncthreads();
     PNP_STAMP(10);
     if (tid == 0) {
-        // refinement unavailable (planar / < 6 inliers): OpenCV reports failure
-        // and hands back the best RANSAC hypothesis
-        for (int j = 0; j < 6; j++) rto[j] = init_ok ? S.param[j] : S.best[j];
+        // no usable DLT solution: OpenCV reports failure and hands back the best RANSAC hypothesis; five
+        // non-planar inliers: that hypothesis is the result
+        for (int j = 0; j < 6; j++) rto[j] = (init_ok && init_mode != 2) ? S.param[j] : S.best[j];
         po[0] = init_ok ? 1 : 0;
         po[1] = init_ok ? k : 0;
         po[2] = S.iter;
