@@ -306,8 +306,9 @@ int vo_match_features_ex(vo_ctx *ctx, const vo_kp *prev_kps, const uint8_t *prev
  * inliers: up to n ascending indices.  The refinement starts from a homography
  * when the inliers are planar (a wall, the floor) and from the DLT otherwise;
  * five non-planar inliers keep the pose of their minimal sample, as in OpenCV.
- * *success is 0 when no hypothesis has more than 4 inliers or when n < 5
- * (OpenCV would use P3P for n == 4).
+ * Exactly four points go to a P3P solve without RANSAC (the fourth point picks
+ * among the solutions of the first three), exactly five to one EPnP solve.
+ * *success is 0 when no hypothesis has more than 4 inliers or when n < 4.
  * reference src/frame_processor.cpp:176-196 */
 int vo_solve_pnp_ransac(vo_ctx *ctx, const float *obj, const float *img, int n,
                         double fx, double fy, double cx, double cy, int iters,

@@ -222,6 +222,9 @@ int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx,
 int ora_epnp(const double *obj, const double *img_norm, int n, double *R,
              double *t);
 
+/* solvePnP(SOLVEPNP_P3P) on four correspondences (obj 4 x 3, img 4 x 2 pixels): R row-major, t */
+int ora_p3p(const double *obj, const double *img, double fx, double fy, double cx, double cy, double *R, double *t);
+
 /* Levenberg-Marquardt pose refinement as solvePnP(SOLVEPNP_ITERATIVE) */
 int ora_pnp_iterative(const double *obj, const double *img, int n, double fx,
                       double fy, double cx, double cy, double *rvec,

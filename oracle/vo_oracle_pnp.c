@@ -988,6 +988,157 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
     return 1;
 }
 
+/* ------------------------------------------------------------------ P3P */
+
+static double p3p_horner(const double *p, int deg, double x)
+{
+    double v = p[deg];
+    for (int i = deg - 1; i >= 0; i--) v = v * x + p[i];
+    return v;
+}
+
+/* ascending real roots (with sign change) of a polynomial of degree <= 4:
+ * the roots of each derivative split [-B, B] (Cauchy bound) into monotone
+ * pieces that are bisected until the interval stops shrinking */
+static int p3p_real_roots4(const double *p_in, double *roots)
+{
+    int deg = 4;
+    while (deg > 0 && p_in[deg] == 0) deg--;
+    if (deg <= 0) return 0;
+    double P[5][5];
+    for (int i = 0; i <= deg; i++) P[deg][i] = p_in[i];
+    for (int d = deg; d > 1; d--)
+        for (int i = 1; i <= d; i++) P[d - 1][i - 1] = P[d][i] * i;
+    double crit[4], cur[4];
+    int nc = 1;
+    crit[0] = -P[1][0] / P[1][1];
+    for (int d = 2; d <= deg; d++) {
+        const double *p = P[d];
+        double bound = 0;
+        for (int i = 0; i < d; i++) bound = fmax(bound, fabs(p[i] / p[d]));
+        bound += 1.0;
+        int n = 0;
+        double lo = -bound, flo = p3p_horner(p, d, lo);
+        for (int k = 0; k <= nc; k++) {
+            double hi = k < nc ? crit[k] : bound;
+            if (hi <= lo) continue;
+            if (hi > bound) hi = bound;
+            const double fhi = p3p_horner(p, d, hi);
+            if (flo == 0) {
+                cur[n++] = lo;
+            } else if (fhi != 0 && (flo < 0) != (fhi < 0)) {
+                double a = lo, b = hi, fa = flo;
+                int exact = 0;
+                for (int it = 0; it < 200; it++) {
+                    const double mid = 0.5 * (a + b);
+                    if (mid == a || mid == b) break;
+                    const double fm = p3p_horner(p, d, mid);
+                    if (fm == 0) { a = b = mid; exact = 1; break; }
+                    if ((fm < 0) == (fa < 0)) { a = mid; fa = fm; }
+                    else b = mid;
+                }
+                cur[n++] = exact ? a : 0.5 * (a + b);
+            }
+            lo = hi;
+            flo = fhi;
+        }
+        if (flo == 0 && n < d) cur[n++] = lo;
+        nc = n;
+        for (int i = 0; i < n; i++) crit[i] = cur[i];
+    }
+    for (int i = 0; i < nc; i++) roots[i] = crit[i];
+    return nc;
+}
+
+/* orthonormal frame of a triangle: e1 along p1 - p0, e3 the normal, e2 = e3 x e1 (rows of F) */
+static int p3p_triangle_frame(const double *p0, const double *p1, const double *p2, double *F)
+{
+    double a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, b[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    double na = sqrt(dot3(a, a));
+    if (na == 0) return 0;
+    for (int i = 0; i < 3; i++) a[i] /= na;
+    double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    double nc = sqrt(dot3(c, c));
+    if (nc == 0) return 0;
+    for (int i = 0; i < 3; i++) c[i] /= nc;
+    double e2[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+    for (int i = 0; i < 3; i++) { F[i] = a[i]; F[3 + i] = e2[i]; F[6 + i] = c[i]; }
+    return 1;
+}
+
+/* cv::solvePnP(SOLVEPNP_P3P) on exactly four correspondences, as
+ * cv::solvePnPRansac runs it when it is handed four points: the (up to four)
+ * poses consistent with the first three points, of which the one that
+ * reprojects the fourth point best is kept.  OpenCV's p3p.cpp follows Gao et
+ * al.; the same solution set is computed here from Grunert's quartic in
+ * v = s3 / s1 (si: distance of point i from the camera), its real roots by
+ * bisection, and the rigid motion between the two triangles.
+ * obj: 4 x 3, img: 4 x 2 pixels.  Returns 1 and R (row-major), t on success. */
+static int p3p_solve4(const double *obj, const double *img, double fx, double fy, double cx, double cy, double *R,
+                      double *t)
+{
+    double j[3][3];
+    for (int i = 0; i < 3; i++) {
+        double x = (img[2 * i] - cx) / fx, y = (img[2 * i + 1] - cy) / fy;
+        double nrm = sqrt(x * x + y * y + 1.0);
+        j[i][0] = x / nrm; j[i][1] = y / nrm; j[i][2] = 1.0 / nrm;
+    }
+    const double a2 = dist2(obj + 3, obj + 6), b2 = dist2(obj, obj + 6), c2 = dist2(obj, obj + 3);
+    if (a2 == 0 || b2 == 0 || c2 == 0) return 0;
+    const double ca = dot3(j[1], j[2]), cb = dot3(j[0], j[2]), cg = dot3(j[0], j[1]);
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2;
+    double q[5];
+    q[4] = (k1 - 1) * (k1 - 1) - 4 * c2 / b2 * ca * ca;
+    q[3] = 4 * (k1 * (1 - k1) * cb - (1 - k2) * ca * cg + 2 * c2 / b2 * ca * ca * cb);
+    q[2] = 2 * (k1 * k1 - 1 + 2 * k1 * k1 * cb * cb + 2 * (b2 - c2) / b2 * ca * ca - 4 * k2 * ca * cb * cg +
+                2 * (b2 - a2) / b2 * cg * cg);
+    q[1] = 4 * (-k1 * (1 + k1) * cb + 2 * a2 / b2 * cg * cg * cb - (1 - k2) * ca * cg);
+    q[0] = (1 + k1) * (1 + k1) - 4 * a2 / b2 * cg * cg;
+    double roots[4];
+    const int nr = p3p_real_roots4(q, roots);
+    double FX[9];
+    if (!p3p_triangle_frame(obj, obj + 3, obj + 6, FX)) return 0;
+    const double Xc[3] = {(obj[0] + obj[3] + obj[6]) / 3, (obj[1] + obj[4] + obj[7]) / 3, (obj[2] + obj[5] + obj[8]) / 3};
+    int found = 0;
+    double best = 0;
+    for (int r = 0; r < nr; r++) {
+        const double v = roots[r];
+        if (!(v > 0)) continue;
+        const double den = 2 * (cg - v * ca);
+        if (den == 0) continue;
+        const double u = ((k1 - 1) * v * v - 2 * k1 * cb * v + 1 + k1) / den;
+        const double w = 1 + v * v - 2 * v * cb;
+        if (!(u > 0) || !(w > 0)) continue;
+        const double s1 = sqrt(b2 / w), s2 = u * s1, s3 = v * s1;
+        double Y[9];
+        for (int i = 0; i < 3; i++) { Y[i] = s1 * j[0][i]; Y[3 + i] = s2 * j[1][i]; Y[6 + i] = s3 * j[2][i]; }
+        double FY[9];
+        if (!p3p_triangle_frame(Y, Y + 3, Y + 6, FY)) continue;
+        double Rc[9], tc[3];
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) Rc[i * 3 + k] = FY[i] * FX[k] + FY[3 + i] * FX[3 + k] + FY[6 + i] * FX[6 + k];
+        for (int i = 0; i < 3; i++) tc[i] = (Y[i] + Y[3 + i] + Y[6 + i]) / 3 - dot3(Rc + 3 * i, Xc);
+        /* the fourth point decides */
+        const double *X3 = obj + 9;
+        const double Xp = dot3(Rc, X3) + tc[0], Yp = dot3(Rc + 3, X3) + tc[1], Zp = dot3(Rc + 6, X3) + tc[2];
+        const double du = cx + fx * Xp / Zp - img[6], dv = cy + fy * Yp / Zp - img[7];
+        const double e = du * du + dv * dv;
+        if (!isfinite(e)) continue;
+        if (!found || e < best) {
+            found = 1;
+            best = e;
+            memcpy(R, Rc, sizeof(Rc));
+            memcpy(t, tc, sizeof(tc));
+        }
+    }
+    return found;
+}
+
+int ora_p3p(const double *obj, const double *img, double fx, double fy, double cx, double cy, double *R, double *t)
+{
+    return p3p_solve4(obj, img, fx, fy, cx, cy, R, t);
+}
+
 /* ------------------------------------------------------- RANSAC driver */
 
 /* [OCV-recall] RANSACUpdateNumIters */
@@ -1025,7 +1176,7 @@ static void pnp_errors(const float *obj, const float *img, int n, double fx, dou
 
 /* [OCV-recall] cv::solvePnPRansac, EPnP on 5-point samples (n > 5), final
  * iterative refinement on the inliers.  With n == 5 OpenCV runs the minimal
- * solver once; n == 4 (P3P) is not restated and reports failure. */
+ * solver once, with n == 4 its P3P solver. */
 int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx, double fy, double cx,
                          double cy, int iters, double thr, double conf, double *rvec, double *tvec,
                          int32_t *inliers, int *n_inliers)
@@ -1033,9 +1184,22 @@ int ora_solve_pnp_ransac(const float *obj, const float *img, int n, double fx, d
     const int model_points = 5;
     if (n_inliers) *n_inliers = 0;
     for (int i = 0; i < 3; i++) rvec[i] = tvec[i] = 0;
+    double so[15], si[10], R[9], t[3];
+    if (n == 4) {
+        /* four points: no RANSAC, one P3P solve, every point reported as inlier */
+        for (int i = 0; i < 4; i++) {
+            for (int j = 0; j < 3; j++) so[3 * i + j] = obj[3 * i + j];
+            si[2 * i] = img[2 * i]; si[2 * i + 1] = img[2 * i + 1];
+        }
+        if (!p3p_solve4(so, si, fx, fy, cx, cy, R, t)) return 0;
+        ora_rodrigues_mat2vec(R, rvec);
+        memcpy(tvec, t, sizeof(t));
+        for (int i = 0; i < 4; i++) inliers[i] = i;
+        *n_inliers = 4;
+        return 1;
+    }
     if (n < model_points) return 0;
 
-    double so[15], si[10], R[9], t[3];
     if (n == model_points) {
         for (int i = 0; i < 5; i++) {
             for (int j = 0; j < 3; j++) so[3 * i + j] = obj[3 * i + j];

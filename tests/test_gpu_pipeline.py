@@ -33,7 +33,7 @@ def _scene_points(rng, n, cam, outlier_frac, noise):
 
 
 @pytest.mark.parametrize("n,outliers,noise", [(400, 0.3, 0.5), (60, 0.0, 0.2), (1500, 0.5, 1.0), (6, 0.0, 0.0),
-                                               (5, 0.0, 0.0), (4, 0.0, 0.0)])
+                                               (5, 0.0, 0.0), (4, 0.0, 0.0), (3, 0.0, 0.0)])
 def test_solve_pnp_ransac(ctx, oracle, n, outliers, noise):
     cam = synth.CONFIG_CAMERAS["hd720"]
     rng = np.random.default_rng(n)
@@ -91,6 +91,28 @@ def test_solve_pnp_ransac_planar_points(ctx, oracle, plane, n, outliers, noise, 
     _assert_pose_close(rv_g, t_g, rv_r, t_r)
     if n >= 40:
         assert np.abs(rv_g - rv).max() < 5e-3 and np.abs(t_g - t).max() < 25.0  # near ground truth
+
+
+def test_solve_pnp_ransac_four_points_p3p(ctx, oracle):
+    """Exactly four points: one P3P solve (solutions from the first three points, the fourth picks), no RANSAC."""
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    rng = np.random.default_rng(4)
+    n_ok = 0
+    for trial in range(40):
+        X, uv, rv, t = _scene_points(rng, 4, cam, 0.0, 0.0)
+        ok_r, rv_r, t_r, inl_r = oracle.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy)
+        ok, rv_g, t_g, inl = ctx.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy)
+        assert ok == ok_r and np.array_equal(inl, inl_r)
+        if ok:
+            n_ok += 1
+            assert list(inl) == [0, 1, 2, 3]
+            _assert_pose_close(rv_g, t_g, rv_r, t_r)
+            # noise-free input: the true pose is among the solutions and the fourth point selects it
+            assert np.abs(rv_g - rv).max() < 2e-3 and np.abs(t_g - t).max() < 10.0
+    assert n_ok >= 38
+    # three points or fewer: failure, as cv::solvePnPRansac reports
+    ok, _, _, inl = ctx.solve_pnp_ransac(X[:3], uv[:3], cam.fx, cam.fy, cam.cx, cam.cy)
+    assert not ok and len(inl) == 0
 
 
 def test_solve_pnp_ransac_five_inliers_keep_minimal_sample_pose(ctx, oracle):
