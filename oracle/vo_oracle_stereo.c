@@ -87,7 +87,7 @@ void ora_stereo_depth_plane(const ora_kp *lk, const float *depth, int nl, int w,
         for (int x = 0; x < w; x++) plane[(size_t)y * stride + x] = NAN;
     for (int i = 0; i < nl; i++) {
         if (isnan(depth[i])) continue;
-        const int u = (int)lrintf(lk[i].x), v = (int)lrintf(lk[i].y);
+        const int u = (int)roundf(lk[i].x), v = (int)roundf(lk[i].y);  /* std::round, as the back-projection samples */
         if (u < 0 || u >= w || v < 0 || v >= h) continue;
         float *p = &plane[(size_t)v * stride + u];
         if (isnan(*p) || depth[i] < *p) *p = depth[i];

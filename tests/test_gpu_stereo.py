@@ -159,3 +159,57 @@ def test_stereo_batch_pipeline(oracle, detector_levels):
             small.close()
     finally:
         ctx.close()
+
+
+def test_stereo_batch_after_reconfigure_to_larger_batch(oracle):
+    """A stereo batch of two frames, then the same context reconfigured to four frames of another size: the depth
+    planes of the new layout must all start as NaN (no stale depth from the first configuration), so every frame
+    still matches the oracle run on the oracle's own sparse planes."""
+    from oracle.pipeline import OracleStream
+    from visual_odometry_amd import capi
+    big, small = synth.CONFIG_CAMERAS["vga"], synth.Camera(320, 240, 260.0, 260.0, 159.5, 119.5)
+    N = 500
+    ctx = capi.Context(0, big.width, big.height, N, 8)
+    try:
+        for cam, B, seed in ((small, 2, 6400), (big, 4, 6500)):
+            K = (cam.fx, cam.fy, cam.cx, cam.cy)
+            scene = synth.Scene(seed, relief=2.0)
+            left = synth.make_sequence(cam, B, seed, 3, scene=scene)["frames"]
+            right = synth.make_sequence(cam, B, seed + 1, 3, scene=scene, baseline_mm=BASELINE_MM)["frames"]
+            ctx.batch_configure(cam.width, cam.height, 3, n_streams=1, frames_per_stream=B, max_features=N, camera=K)
+            ctx.batch_submit_stereo(left, right, BASELINE_MM, band=2.0, min_disp=1.0, max_disp=200.0, ratio=0.8)
+            res = ctx.batch_wait()
+            ref = OracleStream(K, N, 20)
+            for b in range(B):
+                kl, dl = oracle.detect(oracle.gray(left[b]), N, 20)
+                kr, dr = oracle.detect(oracle.gray(right[b]), N, 20)
+                plane = oracle.stereo_match(kl, dl, kr, dr, cam.fx, BASELINE_MM, 2.0, 1.0, 200.0, 0.8,
+                                            size=(cam.width, cam.height))[3]
+                r = ref.process(left[b], plane)
+                m, p3 = ctx.batch_matches(b, 2)
+                assert np.array_equal(m, r["valid"]) and np.array_equal(p3, r["pts3"]), (cam.width, b)
+                assert res["n_3d"][b] == len(r["pts3"])
+    finally:
+        ctx.close()
+
+
+def test_stereo_depth_plane_rounds_like_the_backprojection(ctx, oracle):
+    """Key points of upper pyramid levels have x.5 coordinates when the scale factor is 1.5 (odd level coordinates times 1.5): the sparse depth
+    plane must be written at round-half-away (std::round), where backprojectAndFilter samples it, so every matched
+    left key point finds its own depth again."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    scene = synth.Scene(6600, relief=2.0)
+    left = synth.make_sequence(cam, 1, 6600, 1, scene=scene)["frames"][0]
+    right = synth.make_sequence(cam, 1, 6601, 1, scene=scene, baseline_mm=BASELINE_MM)["frames"][0]
+    kl, dl = ctx.detect_orb(left, 1000, 1.5, 3, 20)
+    kr, dr = ctx.detect_orb(right, 1000, 1.5, 3, 20)
+    assert (np.abs(kl["x"] - np.floor(kl["x"]) - 0.5) < 1e-6).sum() > 20     # half-pixel coordinates exist
+    ref = oracle.stereo_match(kl, dl, kr, dr, cam.fx, BASELINE_MM, size=(cam.width, cam.height))
+    got = ctx.stereo_depth(kl, dl, kr, dr, cam.fx, BASELINE_MM, size=(cam.width, cam.height))
+    assert np.array_equal(got[0], ref[0]) and _nan_equal(got[3], ref[3])
+    plane, matched = got[3], np.flatnonzero(got[0] >= 0)
+    u = np.floor(np.abs(kl["x"][matched]) + 0.5).astype(int)                 # std::round for non-negative values
+    v = np.floor(np.abs(kl["y"][matched]) + 0.5).astype(int)
+    assert len(matched) > 100 and np.isfinite(plane[v, u]).all()
+    # several key points may share a pixel: the nearest depth wins, so the sampled depth is never farther
+    assert (plane[v, u] <= got[2][matched]).all()

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
                                                           const uint32_t *__restrict__ lvl_ras,
                                                           const float *__restrict__ lvl_resp,
                                                           const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
-                                                          int kp_stride, int *__restrict__ nkp)
+                                                          int kp_stride, int kp_cap, int *__restrict__ nkp)
 {
     __shared__ uint32_t s_mask[16][OF_LANES];
     const int f = blockIdx.y, gl = threadIdx.x & (OF_LANES - 1);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
         if (level < 0 && i < total + n) { level = l; j = i - total; }
         total += n;
     }
-    total = min(total, kp_stride);
+    total = min(total, kp_cap);  // vo_cfg.max_features: what the caller's arrays hold (kp_stride is padded)
     if (blockIdx.x == 0 && threadIdx.x == 0) nkp[f] = total;
     const bool live = level >= 0 && i < total;
     const int lv = live ? level : 0;
@@ -701,11 +701,12 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 }
 
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
-                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s)
+                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int kp_cap, int *nkp,
+                       hipStream_t s)
 {
     dim3 grid((kp_stride + OF_KPB - 1) / OF_KPB, batch);
     hipLaunchKernelGGL(k_orb_finish, grid, dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras, lvl_resp, lvl_n, kps,
-                       kp_stride, nkp);
+                       kp_stride, kp_cap, nkp);
 }
 
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,

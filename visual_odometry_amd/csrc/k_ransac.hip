@@ -520,12 +520,9 @@ void launch_f_ransac(const vo_match *good, const int *n_good, int kp_stride, con
                      int pairs, hipStream_t s)
 {
     const size_t lds = ((sizeof(FrShared) + 15) & ~size_t(15)) + sizeof(float4) * (size_t)kp_stride;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_f_ransac),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // per launch: the attribute belongs to the current device's copy of the kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_f_ransac), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     hipLaunchKernelGGL(k_f_ransac, dim3(pairs), dim3(FR_THREADS), lds, s, good, n_good, kp_stride, rng_raw,
                        rng_len, prm, mask, F, info, final_m);
 }

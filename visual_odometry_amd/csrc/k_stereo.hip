@@ -124,7 +124,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_stereo_finalize(const vo_kp *__r
         if (ok) {
             d = lk[i].x - rk[j].x;
             zz = (float)(fx * baseline / (double)d);
-            const int u = (int)rintf(lk[i].x), v = (int)rintf(lk[i].y);
+            const int u = (int)roundf(lk[i].x), v = (int)roundf(lk[i].y);
             if (plane && u >= 0 && u < w && v >= 0 && v < h)
                 atomicMin(&plane[(size_t)z * w * h + (size_t)v * w + u], __float_as_uint(zz));
         } else {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_stereo_clear(const vo_kp *__rest
     const int i = blockIdx.x * ST_THREADS + threadIdx.x;
     if (i >= nl) return;
     const vo_kp kp = kps[(size_t)(l_slot0 + z) * kp_stride + i];
-    const int u = (int)rintf(kp.x), v = (int)rintf(kp.y);
+    const int u = (int)roundf(kp.x), v = (int)roundf(kp.y);
     if (u >= 0 && u < w && v >= 0 && v < h) plane[(size_t)z * w * h + (size_t)v * w + u] = 0xffffffffu;
 }
 

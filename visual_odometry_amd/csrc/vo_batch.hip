@@ -231,6 +231,8 @@ int vo_batch_configure(vo_ctx *c, const vo_batch_cfg *b)
     c->bcfg = *b;
     c->configured = true;
     c->submitted = false;
+    // the NaN fill of the stereo depth planes covers the geometry and batch of the configuration it was made under
+    c->depth_planes_nan = false;
     return vo_batch_reset(c);
 }
 

@@ -182,7 +182,8 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMemcpy(d_pattern, pat, 1024, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMalloc(&d_pattern0, 1024));
     HIP_TRY(ctx, hipMemcpy(d_pattern0, vo_orb_bit_pattern_31, 1024, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipHostMalloc(&h_pinned, kPinnedBytes));
+    pinned_bytes = std::max(kPinnedBytes, sizeof(vo_frame_result) * (size_t)B);
+    HIP_TRY(ctx, hipHostMalloc(&h_pinned, pinned_bytes));
     return VO_OK;
 }
 
@@ -744,7 +745,7 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
     launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_orb_cand_flat, d_lvl_ras, d_lvl_resp,
                       d_lvl_n, stream);
     launch_orb_finish(orb, batch, d_pyr, d_lvl_ras, d_lvl_resp, d_lvl_n, d_kps + (size_t)first_slot * kp_stride,
-                      kp_stride, d_nkp + first_slot, stream);
+                      kp_stride, cfg.max_features, d_nkp + first_slot, stream);
     mark(4);
     launch_brief_steered(orb, batch, d_pyr_blur, d_kps + (size_t)first_slot * kp_stride, kp_stride,
                          d_nkp + first_slot, d_pattern0, d_desc + (size_t)first_slot * kp_stride * 32, stream);

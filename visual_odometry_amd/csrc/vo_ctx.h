@@ -102,6 +102,7 @@ struct vo_ctx {
     }
 
     static constexpr size_t kPinnedBytes = 1 << 20;
+    size_t pinned_bytes = 0;  // max(kPinnedBytes, max_batch result records)
     void *h_pinned = nullptr;
 
     vo::PlaneBatch plane(uint8_t *base) const { return vo::PlaneBatch{base, pitch, plane_bytes}; }

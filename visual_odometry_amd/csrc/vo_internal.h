@@ -68,9 +68,10 @@ void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
                        const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
                        hipStream_t s);
-// concatenate the levels, intensity-centroid angle, cv::KeyPoint records
+// concatenate the levels (at most kp_cap key points per frame), intensity-centroid angle, cv::KeyPoint records
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
-                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int *nkp, hipStream_t s);
+                       const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int kp_cap, int *nkp,
+                       hipStream_t s);
 // rBRIEF-256 steered by each keypoint's angle, sampled on its level's blurred image
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
                           const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s);
