@@ -6,6 +6,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <chrono>
 #include <memory>
 #include <utility>
@@ -75,30 +76,27 @@ public:
                                    want_pose ? (int)(depth.step / sizeof(float)) : 0,
                                    want_pose ? depth.step / sizeof(float) * (size_t)depth.rows : 0),
                    "vo_batch_submit");
-        vo_frame_result r{};
-        dev_.check(vo_batch_wait(ctx, &r), "vo_batch_wait");
-
-        float ms[16] = {0};
-        if (vo_batch_get_timing(ctx, ms) == VO_OK) {
-            result.feature_detection_time = ms[0] + ms[1] + ms[2];
-            result.feature_matching_time = ms[3] + ms[4] + ms[5];
-        }
-
-        int n = 0;
-        dev_.check(vo_batch_get_features(ctx, 0, kps_.data(), desc_.data(), &n), "vo_batch_get_features");
-        detail::to_features(kps_, desc_, n, result.features);
+        dev_.check(vo_batch_wait(ctx, nullptr), "vo_batch_wait");
+        // everything the frame produced arrived with that one wait (packed output in pinned memory)
+        vo_frame_view view{};
+        dev_.check(vo_batch_get_packed(ctx, 0, &view), "vo_batch_get_packed");
+        const vo_frame_result &r = view.result;
+        // detect = gray + FAST/ORB + descriptors, match = kNN + ratio + F-RANSAC + motion filter
+        // (reference src/frame_processor.cpp:30-40), GPU time
+        result.feature_detection_time = view.detect_ms;
+        result.feature_matching_time = view.match_ms;
+        detail::to_features(view.kps, view.desc, view.n_keypoints, result.features);
 
         // reference src/frame_processor.cpp:97,272-307: the match list is replaced
         // by its depth-valid subset only when that subset is not empty
         const int which = r.n_3d > 0 ? 2 : 1;
-        int nm = 0;
-        dev_.check(vo_batch_get_matches(ctx, 0, which, m_.data(), pts3_.data(), &nm), "vo_batch_get_matches");
-        detail::to_matches(m_, nm, result.matches);
+        const int nm = which == 2 ? view.n_valid : view.n_tracked;
+        detail::to_matches(which == 2 ? view.valid : view.tracked, nm, result.matches);
         if (which == 2) {
             result.matches.prev_points_3d.resize((size_t)nm);
             for (int i = 0; i < nm; i++)
                 result.matches.prev_points_3d[(size_t)i] =
-                    cv::Point3f(pts3_[3 * (size_t)i], pts3_[3 * (size_t)i + 1], pts3_[3 * (size_t)i + 2]);
+                    cv::Point3f(view.pts3[3 * (size_t)i], view.pts3[3 * (size_t)i + 1], view.pts3[3 * (size_t)i + 2]);
         }
 
         if (which == 2) {
@@ -164,21 +162,33 @@ private:
 
     void configure(int w, int h, int channels)
     {
-        const bool fresh = dev_.ensure(w, h, kMaxFeatures);
-        if (!fresh && w == w_ && h == h_ && channels == ch_) return;
+        // Default: what the reference's processFrame really runs, FAST + ORB::compute with 1000 / 20 whatever the
+        // setters said.  With the detector switched to DetectorMode::Orb its max_features / scale_factor /
+        // n_levels (the values vo_node forwards, reference src/vo_node.cpp:333-336) configure the full detector.
+        const bool orb = feature_detector_->detectorMode() == DetectorMode::Orb;
+        const int nfeat = orb ? feature_detector_->maxFeatures() : kMaxFeatures;
+        const int levels = orb ? feature_detector_->nLevels() : 0;
+        const float scale = orb ? feature_detector_->scaleFactor() : 0.f;
+        const int cap = orb ? nfeat + 64 : nfeat;  // boundary ties of the per-level ranking
+        const bool fresh = dev_.ensure(w, h, cap);
+        if (!fresh && w == w_ && h == h_ && channels == ch_ && nfeat == nfeat_ && levels == levels_ && scale == scale_)
+            return;
         vo_batch_cfg b{};
         b.width = w; b.height = h; b.channels = channels;
         b.n_streams = 1; b.frames_per_stream = 1;
-        b.max_features = kMaxFeatures; b.fast_threshold = kFastThreshold;
+        b.max_features = nfeat; b.fast_threshold = kFastThreshold;
+        b.orb_levels = levels; b.orb_scale_factor = scale;
         b.ratio = 0.7f;
         b.f_threshold = 3.0; b.f_confidence = 0.99; b.f_max_iters = 1000;
         b.enable_pose = 0;
         b.pnp_iters = 100; b.pnp_threshold = 8.0; b.pnp_confidence = 0.99;
         dev_.check(vo_batch_configure(dev_.get(), &b), "vo_batch_configure");
-        dev_.check(vo_batch_set_timing(dev_.get(), 1), "vo_batch_set_timing");
-        w_ = w; h_ = h; ch_ = channels;
-        kps_.resize(kMaxFeatures); desc_.resize((size_t)kMaxFeatures * 32);
-        m_.resize(kMaxFeatures); pts3_.resize((size_t)kMaxFeatures * 3);
+        // latency path: one packed device-to-host copy per frame, the kernel chain replayed as a HIP graph
+        // (VO_GRAPH=0 launches the kernels one by one)
+        dev_.check(vo_batch_set_packed_output(dev_.get(), 1), "vo_batch_set_packed_output");
+        const char *g = std::getenv("VO_GRAPH");
+        dev_.check(vo_batch_set_graph(dev_.get(), !(g && g[0] == '0')), "vo_batch_set_graph");
+        w_ = w; h_ = h; ch_ = channels; nfeat_ = nfeat; levels_ = levels; scale_ = scale;
     }
 
     // reference src/frame_processor.cpp:99-173: drop features whose reprojection
@@ -237,11 +247,9 @@ private:
     std::shared_ptr<FeatureDetector> feature_detector_;
     std::shared_ptr<FeatureMatcher> feature_matcher_;
     detail::DeviceContext dev_;
-    int w_{0}, h_{0}, ch_{0};
-    std::vector<vo_kp> kps_;
-    std::vector<uint8_t> desc_;
-    std::vector<vo_match> m_;
-    std::vector<float> pts3_, obj_, img_;
+    int w_{0}, h_{0}, ch_{0}, nfeat_{0}, levels_{-1};
+    float scale_{0.f};
+    std::vector<float> obj_, img_;
     std::vector<int32_t> inl_;
 };
 

@@ -79,19 +79,24 @@ inline vo_kp from_cv(const cv::KeyPoint &k)
     return vo_kp{k.pt.x, k.pt.y, k.size, k.angle, k.response, k.octave};
 }
 
-inline void to_features(const std::vector<vo_kp> &kps, const std::vector<uint8_t> &desc, int n, Features &out)
+inline void to_features(const vo_kp *kps, const uint8_t *desc, int n, Features &out)
 {
     out.keypoints.resize((size_t)n);
     for (int i = 0; i < n; i++) out.keypoints[(size_t)i] = to_cv(kps[(size_t)i]);
     if (n > 0) {
         out.descriptors.create(n, 32, CV_8UC1);
-        for (int i = 0; i < n; i++) std::memcpy(out.descriptors.ptr<uint8_t>(i), desc.data() + (size_t)i * 32, 32);
+        for (int i = 0; i < n; i++) std::memcpy(out.descriptors.ptr<uint8_t>(i), desc + (size_t)i * 32, 32);
     } else {
         out.descriptors = cv::Mat();
     }
 }
 
-inline void to_matches(const std::vector<vo_match> &m, int n, FeatureMatches &out)
+inline void to_features(const std::vector<vo_kp> &kps, const std::vector<uint8_t> &desc, int n, Features &out)
+{
+    to_features(kps.data(), desc.data(), n, out);
+}
+
+inline void to_matches(const vo_match *m, int n, FeatureMatches &out)
 {
     out.clear();
     out.reserve((size_t)n);
@@ -101,6 +106,8 @@ inline void to_matches(const std::vector<vo_match> &m, int n, FeatureMatches &ou
         out.curr_points.emplace_back(m[(size_t)i].cx, m[(size_t)i].cy);
     }
 }
+
+inline void to_matches(const std::vector<vo_match> &m, int n, FeatureMatches &out) { to_matches(m.data(), n, out); }
 
 // cv::Rodrigues(rvec) -> 3x3 CV_64F (reference src/frame_processor.cpp:193)
 inline cv::Mat rodrigues_to_matrix(const double r[3])

@@ -409,6 +409,53 @@ int vo_batch_get_matches(vo_ctx *ctx, int frame, int which, vo_match *out,
                          float *pts3, int *n_out);
 int vo_batch_get_inliers(vo_ctx *ctx, int frame, int32_t *inliers, int *n_out);
 
+/* Packed output (latency path).  The reference returns everything by value
+ * from one processFrame call (src/frame_processor.cpp:18-202); fetching the
+ * same through the getters above costs one blocking copy per array.  With
+ * packed output enabled, vo_batch_submit appends one kernel that gathers, for
+ * every frame of the batch, the result record, key points, descriptors, the
+ * three match lists, the 3-D points and the PnP inliers into one block, and
+ * ONE device-to-host copy of all blocks into pinned memory; after
+ * vo_batch_wait(), vo_batch_get_packed() hands out pointers into that memory
+ * (valid until the next submit or configure on this context; no copy, no GPU
+ * call).  detect_ms / match_ms are the GPU times of the detector stages and
+ * of kNN + ratio + F-RANSAC for the whole batch (device wall clock), what the
+ * reference measures around detectFeatures / matchFeatures (:30-40).
+ * Only for small batches: batch x (128 + 156 x feature capacity) bytes may not
+ * exceed 32 MiB (VO_ERR_ARG otherwise). */
+typedef struct {
+    vo_frame_result result;
+    float detect_ms, match_ms;
+    int32_t n_keypoints;
+    const vo_kp *kps;
+    const uint8_t *desc;      /* n_keypoints x 32 */
+    int32_t n_matches, n_tracked, n_valid;
+    const vo_match *matches;  /* FeatureMatcher::match output */
+    const vo_match *tracked;  /* after the track-age filter */
+    const vo_match *valid;    /* with valid depth (the PnP input) */
+    const float *pts3;        /* n_valid x 3 */
+    int32_t n_inliers;
+    const int32_t *inliers;
+} vo_frame_view;
+int vo_batch_set_packed_output(vo_ctx *ctx, int enable);
+int vo_batch_get_packed(vo_ctx *ctx, int frame, vo_frame_view *view);
+
+/* Replay the kernel chain of a batch as one captured HIP graph instead of
+ * launching its 10 to 30 kernels one by one (no counterpart in the reference;
+ * it shortens the launch-bound single-frame path).  The graph is captured on
+ * the first submit after enabling and again whenever the configuration, the
+ * camera or the device input pointers change; host inputs go through the
+ * context's staging area and never force a re-capture.  Per-stage event
+ * timing (vo_batch_set_timing) is ignored while a graph is in use. */
+int vo_batch_set_graph(vo_ctx *ctx, int enable);
+
+/* Pinned host memory for frames and depth planes: vo_batch_submit copies from
+ * such memory by DMA without the staging pass that ordinary (pageable) memory
+ * needs.  A camera wrapper that owns its buffers (the reference clones every
+ * frame into a queue, src/vo_node.cpp:581-588) can clone into these instead. */
+void *vo_host_alloc(size_t bytes);
+void vo_host_free(void *p);
+
 /* Per-kernel timing of vo_batch_submit (measurement aid; the reference only
  * clocks detect and match as a whole, src/frame_processor.cpp:30-40).  When
  * enabled, HIP events are recorded on the context's stream around every

@@ -55,6 +55,14 @@ RESULT_DTYPE = np.dtype([("n_keypoints", "<i4"), ("n_ratio", "<i4"), ("f_found",
                          ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,))])
 
 
+class VoFrameView(C.Structure):
+    _fields_ = [("result", C.c_uint8 * 96), ("detect_ms", C.c_float), ("match_ms", C.c_float),
+                ("n_keypoints", C.c_int32), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("n_matches", C.c_int32), ("n_tracked", C.c_int32), ("n_valid", C.c_int32),
+                ("matches", C.c_void_p), ("tracked", C.c_void_p), ("valid", C.c_void_p), ("pts3", C.c_void_p),
+                ("n_inliers", C.c_int32), ("inliers", C.c_void_p)]
+
+
 class VoError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libvo_hip error {code}: {msg}")
@@ -108,6 +116,11 @@ EXPORTS = {
     "vo_batch_get_matches": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vo_batch_get_inliers": (C.c_int, [_P, C.c_int, _P, _P]),
     "vo_batch_set_timing": (C.c_int, [_P, C.c_int]),
+    "vo_batch_set_packed_output": (C.c_int, [_P, C.c_int]),
+    "vo_batch_get_packed": (C.c_int, [_P, C.c_int, _P]),
+    "vo_batch_set_graph": (C.c_int, [_P, C.c_int]),
+    "vo_host_alloc": (_P, [C.c_size_t]),
+    "vo_host_free": (None, [_P]),
     "vo_set_matcher": (C.c_int, [_P, C.c_int]),
     "vo_batch_stage_count": (C.c_int, []),
     "vo_batch_stage_name": (C.c_char_p, [C.c_int]),
@@ -456,6 +469,30 @@ class Context:
         n = C.c_int(0)
         self._check(self._lib.vo_batch_get_inliers(self._h, frame, _ptr(out), C.addressof(n)))
         return out[:n.value].copy()
+
+    def batch_set_packed_output(self, enable: bool):
+        self._check(self._lib.vo_batch_set_packed_output(self._h, int(enable)))
+
+    def batch_set_graph(self, enable: bool):
+        self._check(self._lib.vo_batch_set_graph(self._h, int(enable)))
+
+    def batch_packed(self, frame: int) -> dict:
+        """Everything of one frame of the last batch from the packed output block (copies out of pinned memory)."""
+        v = VoFrameView()
+        self._check(self._lib.vo_batch_get_packed(self._h, frame, C.byref(v)))
+
+        def arr(ptr, n, dtype, shape=None):
+            if n <= 0:
+                return np.zeros((0,) + (shape or ()), dtype)
+            nbytes = n * np.dtype(dtype).itemsize * (int(np.prod(shape)) if shape else 1)
+            a = np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype)
+            return a.reshape((n,) + shape) if shape else a
+        return {"result": np.frombuffer(bytes(v.result), RESULT_DTYPE)[0], "detect_ms": v.detect_ms,
+                "match_ms": v.match_ms, "kps": arr(v.kps, v.n_keypoints, KP_DTYPE),
+                "desc": arr(v.desc, v.n_keypoints, np.uint8, (32,)),
+                "matches": arr(v.matches, v.n_matches, MATCH_DTYPE), "tracked": arr(v.tracked, v.n_tracked, MATCH_DTYPE),
+                "valid": arr(v.valid, v.n_valid, MATCH_DTYPE), "pts3": arr(v.pts3, v.n_valid, np.float32, (3,)),
+                "inliers": arr(v.inliers, v.n_inliers, np.int32)}
 
     def set_matcher(self, kind: str):
         """'mfma' (default): all-pairs Hamming distances on the matrix cores; 'popcount': XOR + popcount on the

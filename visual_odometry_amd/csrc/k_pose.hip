@@ -294,6 +294,46 @@ __global__ void k_collect(const int *__restrict__ nkp, const int *__restrict__ t
     out[b] = r;
 }
 
+__global__ void k_stamp(unsigned long long *out)
+{
+    if (threadIdx.x == 0) *out = wall_clock64();
+}
+
+void launch_stamp(unsigned long long *out, hipStream_t s) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, out); }
+
+// One block per frame: everything a caller reads back after a batch, gathered into one block of `out` so that a
+// single device-to-host copy delivers it.  All records are whole 32-bit words.
+__global__ __launch_bounds__(256) void k_pack_frames(PackSrc p, PackLayout L, uint8_t *__restrict__ out)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    uint8_t *dst = out + (size_t)f * L.frame_bytes;
+    const vo_frame_result r = p.res[f];
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(dst);
+    const uint32_t *rs = reinterpret_cast<const uint32_t *>(p.res + f);
+    if (tid < (int)(sizeof(vo_frame_result) / 4)) hdr[tid] = rs[tid];
+    if (tid < 6) hdr[sizeof(vo_frame_result) / 4 + tid] = reinterpret_cast<const uint32_t *>(p.stamps)[tid];
+    const int slot = p.t_slot[f];
+    auto copy_words = [&](size_t off, const void *src, int words) {
+        uint32_t *d = reinterpret_cast<uint32_t *>(dst + off);
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+        for (int i = tid; i < words; i += 256) d[i] = s[i];
+    };
+    const int nk = min(r.n_keypoints, L.cap);
+    copy_words(L.off_kps, p.kps + (size_t)slot * p.kp_stride, nk * (int)(sizeof(vo_kp) / 4));
+    copy_words(L.off_desc, p.desc + (size_t)slot * p.kp_stride * 32, nk * 8);
+    const int nm[3] = {min(r.n_matches, L.cap), min(r.n_tracked, L.cap), min(r.n_3d, L.cap)};
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+        copy_words(L.off_m[w], p.m[w] + (size_t)f * p.kp_stride, nm[w] * (int)(sizeof(vo_match) / 4));
+    copy_words(L.off_pts3, p.pts3 + (size_t)f * p.kp_stride * 3, nm[2] * 3);
+    copy_words(L.off_inl, p.inliers + (size_t)f * p.kp_stride, min(r.pnp_inliers, L.cap));
+}
+
+void launch_pack_frames(const PackSrc &src, PackLayout layout, uint8_t *out, int batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pack_frames, dim3(batch), dim3(256), 0, s, src, layout, out);
+}
+
 void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const int *info,
                     const int *bp_info, const int *pose, const double *rt, vo_frame_result *out, int batch,
                     hipStream_t s)

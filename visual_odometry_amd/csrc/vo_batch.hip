@@ -29,6 +29,8 @@ static int bfail(vo_ctx *ctx, int code, const char *fmt, ...)
                          __FILE__, __LINE__);                                                     \
     } while (0)
 
+static int ensure_pack(vo_ctx *c, int B);
+
 static bool is_device_ptr(const void *p)
 {
     hipPointerAttribute_t a;
@@ -231,6 +233,12 @@ int vo_batch_configure(vo_ctx *c, const vo_batch_cfg *b)
     c->bcfg = *b;
     c->configured = true;
     c->submitted = false;
+    c->drop_graph();
+    c->packed_valid = false;
+    if (c->packed) {
+        const int rc = ensure_pack(c, b->n_streams * b->frames_per_stream);
+        if (rc) return rc;
+    }
     // the NaN fill of the stereo depth planes covers the geometry and batch of the configuration it was made under
     c->depth_planes_nan = false;
     return vo_batch_reset(c);
@@ -261,6 +269,58 @@ int vo_batch_reset(vo_ctx *c)
     HIP_TRY(c, hipMemset(c->d_pose, 0, sizeof(int) * 4 * B));
     HIP_TRY(c, hipMemset(c->d_rt, 0, sizeof(double) * 6 * B));
     HIP_TRY(c, hipMemset(c->d_bpinfo, 0, sizeof(int) * 2 * B));
+    return VO_OK;
+}
+
+// buffers of the packed output for a batch of B frames
+static int ensure_pack(vo_ctx *c, int B)
+{
+    c->pack = pack_layout(c->kp_stride);
+    const size_t need = c->pack.frame_bytes * (size_t)B;
+    if (need > vo_ctx::kPackMaxBytes)
+        return bfail(c, VO_ERR_ARG, "packed output: %d frames x %zu bytes exceed %zu bytes", B, c->pack.frame_bytes,
+                     vo_ctx::kPackMaxBytes);
+    if (need > c->pack_cap_bytes) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->drop_graph();
+        if (c->d_pack) (void)hipFree(c->d_pack);
+        if (c->h_pack) (void)hipHostFree(c->h_pack);
+        c->d_pack = nullptr; c->h_pack = nullptr; c->pack_cap_bytes = 0;
+        HIP_TRY(c, hipMalloc(&c->d_pack, need));
+        HIP_TRY(c, hipHostMalloc(&c->h_pack, need));
+        c->pack_cap_bytes = need;
+    }
+    if (!c->d_stamps) {
+        HIP_TRY(c, hipMalloc(&c->d_stamps, 3 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_stamps, 0, 3 * sizeof(unsigned long long)));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0)
+            khz = 100000;  // the constant 100 MHz counter of gfx9
+        c->wall_clock_khz = khz;
+    }
+    return VO_OK;
+}
+
+// Host planes (count x rows x row_bytes, rows row_stride and planes plane_stride bytes apart) into a packed device
+// area.  Packed input goes up as ONE linear copy, planes with packed rows as one copy each; only padded rows
+// take the 2-D path (which the runtime executes row by row: 13 ms for one HD720 BGRA + depth pair against
+// 1 ms for the two linear copies).
+static int upload_planes(vo_ctx *c, uint8_t *dst, const uint8_t *src, size_t row_bytes, int rows, size_t row_stride,
+                         size_t plane_stride, int count)
+{
+    const size_t plane_bytes = row_bytes * (size_t)rows;
+    if (row_stride == row_bytes && (count == 1 || plane_stride == plane_bytes)) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, plane_bytes * count, hipMemcpyHostToDevice, c->stream));
+        return VO_OK;
+    }
+    for (int i = 0; i < count; i++) {
+        if (row_stride == row_bytes)
+            HIP_TRY(c, hipMemcpyAsync(dst + i * plane_bytes, src + i * plane_stride, plane_bytes, hipMemcpyHostToDevice,
+                                      c->stream));
+        else
+            HIP_TRY(c, hipMemcpy2DAsync(dst + i * plane_bytes, row_bytes, src + i * plane_stride, row_stride, row_bytes,
+                                        rows, hipMemcpyHostToDevice, c->stream));
+    }
     return VO_OK;
 }
 
@@ -307,10 +367,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const bool right_on_host = right && !is_device_ptr(right);
     const uint8_t *src = frames;
     if (!is_device_ptr(frames)) {
-        for (int i = 0; i < B; i++)
-            HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)i * row_bytes * b.height, row_bytes,
-                                        frames + i * frame_stride, row_stride, row_bytes, b.height,
-                                        hipMemcpyHostToDevice, c->stream));
+        int rc0 = upload_planes(c, c->d_in, frames, row_bytes, b.height, row_stride, frame_stride, B);
+        if (rc0) return rc0;
         src = c->d_in;
         row_stride = row_bytes;
         frame_stride = (size_t)row_bytes * b.height;
@@ -318,19 +376,17 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const uint8_t *rsrc = right;
     if (right_on_host) {
         uint8_t *stage = c->d_in + (size_t)B * row_bytes * b.height;  // second half of the staging area
-        for (int i = 0; i < B; i++)
-            HIP_TRY(c, hipMemcpy2DAsync(stage + (size_t)i * row_bytes * b.height, row_bytes,
-                                        right + i * frame_stride_in, row_stride_in, row_bytes,
-                                        b.height, hipMemcpyHostToDevice, c->stream));
+        int rc0 = upload_planes(c, stage, right, row_bytes, b.height, row_stride_in, frame_stride_in, B);
+        if (rc0) return rc0;
         rsrc = stage;
     }
     const float *dsrc = depth;
     if (depth && b.enable_pose && !is_device_ptr(depth)) {
         c->depth_planes_nan = false;
-        for (int i = 0; i < B; i++)
-            HIP_TRY(c, hipMemcpy2DAsync(c->d_depth + (size_t)i * b.width * b.height, sizeof(float) * b.width,
-                                        depth + i * depth_frame_stride, sizeof(float) * depth_row_stride,
-                                        sizeof(float) * b.width, b.height, hipMemcpyHostToDevice, c->stream));
+        int rc0 = upload_planes(c, reinterpret_cast<uint8_t *>(c->d_depth), reinterpret_cast<const uint8_t *>(depth),
+                                sizeof(float) * b.width, b.height, sizeof(float) * depth_row_stride,
+                                sizeof(float) * depth_frame_stride, B);
+        if (rc0) return rc0;
         dsrc = c->d_depth;
         depth_row_stride = b.width;
         depth_frame_stride = (size_t)b.width * b.height;
@@ -338,80 +394,129 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     if (!b.enable_pose) dsrc = nullptr;
     const int r_slot0 = S + B;  // feature slots of the right images
     int rc;
+    // everything that may allocate or synchronise happens before the kernel chain (which may be recorded as a graph)
     if (right) {
         if ((rc = c->ensure_stereo())) return rc;
         if (!c->depth_planes_nan) {
             HIP_TRY(c, hipMemsetAsync(c->d_depth, 0xff, sizeof(float) * (size_t)b.width * b.height * B, c->stream));
             c->depth_planes_nan = true;
         }
-        // the right images first, without timing marks: the marks of the detector stages are the left images'
-        const int rs = right_on_host ? row_bytes : row_stride_in;
-        const size_t fs = right_on_host ? (size_t)row_bytes * b.height : frame_stride_in;
-        c->marks_on = false;
-        if (b.orb_levels > 0) {
-            if ((rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f, b.orb_levels,
-                                    b.max_features, B)))
-                return rc;
-            c->enqueue_detect_orb(rsrc, b.width, b.height, rs, fs, b.channels, b.fast_threshold, B, r_slot0);
-        } else
-            c->enqueue_detect(rsrc, b.width, b.height, rs, fs, b.channels, b.max_features, b.fast_threshold, B, r_slot0);
-        c->marks_on = true;
         dsrc = c->d_depth;
         depth_row_stride = b.width;
         depth_frame_stride = (size_t)b.width * b.height;
     }
-
     if (b.orb_levels > 0) {
         // a single-frame ORB operator call may have re-planned the pyramid since configure
         rc = c->ensure_orb(b.width, b.height, b.orb_scale_factor > 0 ? b.orb_scale_factor : 1.2f, b.orb_levels,
                            b.max_features, B);
         if (rc) return rc;
-        c->enqueue_detect_orb(src, b.width, b.height, row_stride, frame_stride, b.channels, b.fast_threshold, B,
-                              /*first_slot=*/S);
-    } else
-        c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
-                          b.fast_threshold, B, /*first_slot=*/S);
-    if (right) {
-        // depth planes of the batch from the left / right key points (the kNN partial buffers are free until
-        // the temporal matcher runs)
-        HIP_TRY(c, hipMemsetAsync(c->d_st_n, 0, sizeof(int) * B, c->stream));
-        launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, S, r_slot0, B, st->band, st->min_disparity,
-                            st->max_disparity, st->ratio, b.fx, st->baseline, kKnnSplits, c->d_partial, c->d_partial_rev,
-                            c->d_st_idx, c->d_st_disp, c->d_st_depth, reinterpret_cast<uint32_t *>(c->d_depth), b.width,
-                            b.height, c->d_st_n, c->stream);
     }
-    c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
-    c->mark(8);
-    launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
-                      c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
-    c->mark(9);
-    launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
-                              c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
-                              depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
-                              c->d_bpinfo, B, c->stream);
-    if (right)  // the planes go back to all-NaN for the next stereo batch
-        launch_stereo_clear(c->d_kps, c->d_nkp, c->kp_stride, S, B, reinterpret_cast<uint32_t *>(c->d_depth), b.width,
-                            b.height, c->stream);
-    c->mark(10);
-    if (!(b.enable_pose && dsrc)) {
-        HIP_TRY(c, hipMemsetAsync(c->d_pose, 0, sizeof(int) * 4 * B, c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_rt, 0, sizeof(double) * 6 * B, c->stream));
-    } else
-        launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
-                          b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
-                          c->d_rt, B, c->stream);
-    c->mark(11);
-    launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
-                   c->stream);
-    launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
-    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost,
-                              c->stream));
-    c->mark(12);
+    if (c->packed && (rc = ensure_pack(c, B))) return rc;
+    const int rs = right_on_host ? row_bytes : row_stride_in;
+    const size_t fs = right_on_host ? (size_t)row_bytes * b.height : frame_stride_in;
+
+    auto chain = [&]() {
+        if (c->packed) launch_stamp(c->d_stamps, c->stream);
+        if (right) {
+            // the right images first, without timing marks: the marks of the detector stages are the left images'
+            c->marks_on = false;
+            if (b.orb_levels > 0)
+                c->enqueue_detect_orb(rsrc, b.width, b.height, rs, fs, b.channels, b.fast_threshold, B, r_slot0);
+            else
+                c->enqueue_detect(rsrc, b.width, b.height, rs, fs, b.channels, b.max_features, b.fast_threshold, B,
+                                  r_slot0);
+            c->marks_on = true;
+        }
+        if (b.orb_levels > 0)
+            c->enqueue_detect_orb(src, b.width, b.height, row_stride, frame_stride, b.channels, b.fast_threshold, B,
+                                  /*first_slot=*/S);
+        else
+            c->enqueue_detect(src, b.width, b.height, row_stride, frame_stride, b.channels, b.max_features,
+                              b.fast_threshold, B, /*first_slot=*/S);
+        if (right) {
+            // depth planes of the batch from the left / right key points (the kNN partial buffers are free until
+            // the temporal matcher runs)
+            (void)hipMemsetAsync(c->d_st_n, 0, sizeof(int) * B, c->stream);
+            launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, S, r_slot0, B, st->band,
+                                st->min_disparity, st->max_disparity, st->ratio, b.fx, st->baseline, kKnnSplits,
+                                c->d_partial, c->d_partial_rev, c->d_st_idx, c->d_st_disp, c->d_st_depth,
+                                reinterpret_cast<uint32_t *>(c->d_depth), b.width, b.height, c->d_st_n, c->stream);
+        }
+        if (c->packed) launch_stamp(c->d_stamps + 1, c->stream);
+        c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
+        c->mark(8);
+        if (c->packed) launch_stamp(c->d_stamps + 2, c->stream);
+        launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
+                          c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
+        c->mark(9);
+        launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
+                                  c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
+                                  depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
+                                  c->d_bpinfo, B, c->stream);
+        if (right)  // the planes go back to all-NaN for the next stereo batch
+            launch_stereo_clear(c->d_kps, c->d_nkp, c->kp_stride, S, B, reinterpret_cast<uint32_t *>(c->d_depth),
+                                b.width, b.height, c->stream);
+        c->mark(10);
+        if (!(b.enable_pose && dsrc)) {
+            (void)hipMemsetAsync(c->d_pose, 0, sizeof(int) * 4 * B, c->stream);
+            (void)hipMemsetAsync(c->d_rt, 0, sizeof(double) * 6 * B, c->stream);
+        } else
+            launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
+                              b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
+                              c->d_rt, B, c->stream);
+        c->mark(11);
+        launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
+                       c->stream);
+        if (c->packed) {
+            PackSrc ps{c->d_results, c->d_kps, c->d_desc, c->d_tslot, {c->d_final, c->d_tracked, c->d_valid},
+                       c->d_pts3, c->d_inliers, c->d_stamps, c->kp_stride};
+            launch_pack_frames(ps, c->pack, c->d_pack, B, c->stream);
+        }
+        launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
+        (void)hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost, c->stream);
+        if (c->packed)
+            (void)hipMemcpyAsync(c->h_pack, c->d_pack, c->pack.frame_bytes * B, hipMemcpyDeviceToHost, c->stream);
+        c->mark(12);
+    };
+
+    if (c->use_graph) {
+        vo_ctx::GraphKey key{};
+        key.frames = src; key.depth = dsrc; key.right = rsrc;
+        key.row_stride = row_stride; key.depth_row_stride = depth_row_stride;
+        key.frame_stride = frame_stride; key.depth_frame_stride = depth_frame_stride;
+        key.cfg = b;
+        if (st) key.st = *st;
+        key.packed = c->packed; key.popcount = c->matcher_popcount; key.linked = c->first_pairs_linked;
+        if (!c->graph_exec || memcmp(&key, &c->graph_key, sizeof(key)) != 0) {
+            c->drop_graph();
+            hipGraph_t graph = nullptr;
+            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            c->capturing = true;
+            chain();
+            c->capturing = false;
+            hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+            if (ce != hipSuccess || !graph) {
+                (void)hipGetLastError();
+                return bfail(c, VO_ERR_HIP, "vo_batch_submit: graph capture failed: %s", hipGetErrorString(ce));
+            }
+            ce = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ce != hipSuccess) {
+                c->graph_exec = nullptr;
+                return bfail(c, VO_ERR_HIP, "vo_batch_submit: hipGraphInstantiate: %s", hipGetErrorString(ce));
+            }
+            c->graph_key = key;
+        }
+        HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
+    } else {
+        chain();
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));
     c->submitted = true;
     c->streams_started = true;
     c->last_batch_stereo = right != nullptr;
+    c->packed_valid = c->packed;
     return VO_OK;
 }
 
@@ -483,6 +588,76 @@ int vo_batch_set_previous(vo_ctx *c, int stream, const vo_kp *kps, const uint8_t
     c->streams_started = true;
     c->first_pairs_linked = true;
     return VO_OK;
+}
+
+int vo_batch_set_packed_output(vo_ctx *c, int enable)
+{
+    if (!c) return VO_ERR_ARG;
+    if (c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_set_packed_output: a batch is in flight");
+    if (enable && c->configured) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        const int rc = ensure_pack(c, c->bcfg.n_streams * c->bcfg.frames_per_stream);
+        if (rc) return rc;
+    }
+    c->packed = enable != 0;
+    c->packed_valid = false;
+    return VO_OK;
+}
+
+int vo_batch_get_packed(vo_ctx *c, int frame, vo_frame_view *view)
+{
+    if (!c || !view) return VO_ERR_ARG;
+    if (!c->configured || c->submitted || !c->packed_valid)
+        return bfail(c, VO_ERR_STATE, "vo_batch_get_packed: no completed batch with packed output");
+    if (frame < 0 || frame >= c->bcfg.n_streams * c->bcfg.frames_per_stream)
+        return bfail(c, VO_ERR_ARG, "vo_batch_get_packed: frame %d out of range", frame);
+    const PackLayout &L = c->pack;
+    const uint8_t *base = static_cast<const uint8_t *>(c->h_pack) + (size_t)frame * L.frame_bytes;
+    memcpy(&view->result, base, sizeof(vo_frame_result));
+    unsigned long long st[3];
+    memcpy(st, base + sizeof(vo_frame_result), sizeof(st));
+    view->detect_ms = (float)((double)(st[1] - st[0]) / c->wall_clock_khz);
+    view->match_ms = (float)((double)(st[2] - st[1]) / c->wall_clock_khz);
+    const vo_frame_result &r = view->result;
+    auto cl = [&](int n) { return n < L.cap ? (n < 0 ? 0 : n) : L.cap; };
+    view->n_keypoints = cl(r.n_keypoints);
+    view->kps = reinterpret_cast<const vo_kp *>(base + L.off_kps);
+    view->desc = base + L.off_desc;
+    view->n_matches = cl(r.n_matches); view->n_tracked = cl(r.n_tracked); view->n_valid = cl(r.n_3d);
+    view->matches = reinterpret_cast<const vo_match *>(base + L.off_m[0]);
+    view->tracked = reinterpret_cast<const vo_match *>(base + L.off_m[1]);
+    view->valid = reinterpret_cast<const vo_match *>(base + L.off_m[2]);
+    view->pts3 = reinterpret_cast<const float *>(base + L.off_pts3);
+    view->n_inliers = cl(r.pnp_inliers);
+    view->inliers = reinterpret_cast<const int32_t *>(base + L.off_inl);
+    return VO_OK;
+}
+
+int vo_batch_set_graph(vo_ctx *c, int enable)
+{
+    if (!c) return VO_ERR_ARG;
+    if (c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_set_graph: a batch is in flight");
+    c->use_graph = enable != 0;
+    if (!enable) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        c->drop_graph();
+    }
+    return VO_OK;
+}
+
+void *vo_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void vo_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int vo_batch_wait(vo_ctx *c, vo_frame_result *results)

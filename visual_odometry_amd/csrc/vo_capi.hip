@@ -199,6 +199,10 @@ void vo_ctx::release()
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ev)
         if (e) (void)hipEventDestroy(e);
+    drop_graph();
+    if (d_pack) (void)hipFree(d_pack);
+    if (d_stamps) (void)hipFree(d_stamps);
+    if (h_pack) (void)hipHostFree(h_pack);
     if (h_pinned) (void)hipHostFree(h_pinned);
     if (stream) (void)hipStreamDestroy(stream);
 }

@@ -92,13 +92,41 @@ struct vo_ctx {
     int op_slot0 = 0, op_slot1 = 0;   // feature slots used by the single-frame operators
     int empty_slot = 0;            // feature slot that always holds 0 keypoints
 
+    // packed output and graph replay of the batched pipeline (latency path)
+    static constexpr size_t kPackMaxBytes = 32u << 20;
+    bool packed = false;
+    bool packed_valid = false;            // h_pack holds the last completed batch
+    vo::PackLayout pack{};
+    uint8_t *d_pack = nullptr;
+    void *h_pack = nullptr;
+    size_t pack_cap_bytes = 0;            // bytes allocated behind d_pack / h_pack
+    unsigned long long *d_stamps = nullptr;
+    double wall_clock_khz = 0;
+    bool use_graph = false;
+    hipGraphExec_t graph_exec = nullptr;
+    // what the captured graph was built for
+    struct GraphKey {
+        const void *frames, *depth, *right;
+        int row_stride, depth_row_stride;
+        size_t frame_stride, depth_frame_stride;
+        vo_batch_cfg cfg;
+        vo_stereo_cfg st;
+        bool packed, popcount, linked;
+    } graph_key{};
+    void drop_graph()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+    }
+
     // optional per-stage timing of the batched pipeline (HIP events on `stream`)
     static constexpr int kStages = 12;
     bool timing = false;
+    bool capturing = false;  // the stream is recording a graph: no event records
     hipEvent_t ev[kStages + 1] = {};
     void mark(int i)
     {
-        if (timing && marks_on) (void)hipEventRecord(ev[i], stream);
+        if (timing && marks_on && !capturing) (void)hipEventRecord(ev[i], stream);
     }
 
     static constexpr size_t kPinnedBytes = 1 << 20;

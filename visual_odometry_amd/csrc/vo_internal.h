@@ -218,6 +218,41 @@ void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const 
                     const int *bp_info, const int *pose, const double *rt, vo_frame_result *out, int batch,
                     hipStream_t s);
 
+// Packed per-frame output block: header (vo_frame_result + three device wall-clock stamps), then the arrays at
+// fixed offsets for `cap` (a multiple of 8) records each.
+struct PackLayout {
+    int cap;
+    size_t off_kps, off_desc, off_m[3], off_pts3, off_inl, frame_bytes;
+};
+inline PackLayout pack_layout(int cap)
+{
+    PackLayout L;
+    L.cap = cap;
+    L.off_kps = 128;
+    L.off_desc = L.off_kps + sizeof(vo_kp) * (size_t)cap;
+    L.off_m[0] = L.off_desc + 32 * (size_t)cap;
+    L.off_m[1] = L.off_m[0] + sizeof(vo_match) * (size_t)cap;
+    L.off_m[2] = L.off_m[1] + sizeof(vo_match) * (size_t)cap;
+    L.off_pts3 = L.off_m[2] + sizeof(vo_match) * (size_t)cap;
+    L.off_inl = L.off_pts3 + 12 * (size_t)cap;
+    L.frame_bytes = L.off_inl + 4 * (size_t)cap;
+    return L;
+}
+struct PackSrc {
+    const vo_frame_result *res;
+    const vo_kp *kps;       // slot 0 of the feature slots
+    const uint8_t *desc;
+    const int *t_slot;      // feature slot of each frame
+    const vo_match *m[3];   // final, tracked, valid
+    const float *pts3;
+    const int *inliers;
+    const unsigned long long *stamps;  // 3 device wall-clock values of the batch
+    int kp_stride;
+};
+void launch_pack_frames(const PackSrc &src, PackLayout layout, uint8_t *out, int batch, hipStream_t s);
+// store the device wall clock (constant-rate counter) in *out
+void launch_stamp(unsigned long long *out, hipStream_t s);
+
 #ifdef __HIPCC__
 // Corner keys: (255 - score) << 24 | y << 12 | x.  Ascending key order is score descending, then raster order
 // (frames are at most kMaxDim = 4096 wide and high, so x and y take 12 bits each).
