@@ -34,7 +34,7 @@ HARD_SCENE_MOVERS = 30       # independently moving rectangles of the hard scene
                              # survivors then violate the camera's epipolar geometry)
 
 
-def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0):
+def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0, tilt=(0.0, 0.0)):
     """`streams` independent HD720 BGRA + depth streams (stream s is rendered from seed + s: its own scene,
     texture and noise), `frames` consecutive frames each, walking forth and back over frames/2 + 1 camera
     positions so that a launch can be repeated.  Returns the camera, the frames and depth planes in batch order
@@ -42,7 +42,7 @@ def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0):
     from visual_odometry_amd import synth
     cam = synth.CONFIG_CAMERAS["hd720"]
     f, d, truth = synth.make_pingpong_batch(cam, streams, frames, seed, channels=4, relief=relief, movers=movers,
-                                            workers=workers)
+                                            workers=workers, tilt=tilt)
     return cam, f, d, truth
 
 
@@ -139,6 +139,9 @@ def main():
                     help="also run the same launch on streams with independently moving objects (0 = skip)")
     ap.add_argument("--flat-scene", type=int, default=1,
                     help="also run the same launch on streams that look at a flat wall (0 = skip)")
+    ap.add_argument("--host-fed", type=int, default=1, help="also measure the host-fed (PCIe-inclusive) rate (0 = skip)")
+    ap.add_argument("--facade-latency", type=int, default=1,
+                    help="also measure the single-stream latency through the C++ facade (0 = skip)")
     ap.add_argument("--cpu-fast", type=int, default=1,
                     help="also time the CPU baseline of the other detector (the one-level FAST sequence the "
                          "reference node runs) for the record (0 = skip)")
@@ -265,12 +268,62 @@ def main():
         hard["median_translation_error_mm"] = float(np.median(t_err)) if t_err else None
         del hf, hd, hin
 
+    # Host-fed throughput: the same launches with every frame and depth plane coming from (pinned) host memory,
+    # the upload of launch k+1 running on a copy stream under the kernels of launch k.  PCIe-bound; never `value`.
+    host_fed = None
+    if args.host_fed and world == 1:
+        hs = min(S, 8)                       # streams of the host-fed launches (keeps the pinned buffers below 1 GB)
+        hb = hs * F
+        fp_ = torch.from_numpy(frames_h[:hb]).pin_memory()
+        dp_ = torch.from_numpy(depth_h[:hb]).pin_memory()
+        bufs = [(torch.empty_like(fp_, device="cuda"), torch.empty_like(dp_, device="cuda")) for _ in range(2)]
+        hctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=hb)
+        hctx.set_matcher(args.matcher)
+        hctx.batch_configure(W, H, C, n_streams=hs, frames_per_stream=F, max_features=args.features,
+                             fast_threshold=20, camera=K, orb_levels=levels)
+        copy_stream = torch.cuda.Stream()
+
+        def upload(k):
+            with torch.cuda.stream(copy_stream):
+                bufs[k % 2][0].copy_(fp_, non_blocking=True)
+                bufs[k % 2][1].copy_(dp_, non_blocking=True)
+
+        def run_launch(k):
+            fb, db = bufs[k % 2]
+            hctx.batch_submit_ptr(fb.data_ptr(), W * C, W * C * H, db.data_ptr(), W, W * H)
+
+        n_h = max(4, args.steps // 2)
+        upload(0)
+        copy_stream.synchronize()
+        run_launch(0); upload(1); hctx.batch_wait(); copy_stream.synchronize()   # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, n_h + 1):
+            run_launch(k)          # kernels of launch k ...
+            upload(k + 1)          # ... while launch k+1 comes up over PCIe
+            hres = hctx.batch_wait()
+            copy_stream.synchronize()
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t0
+        bytes_per_launch = fp_.numel() + 4 * dp_.numel()
+        host_fed = {"value": hb * n_h / dt_h, "unit": "frames/s", "frames_per_launch": hb, "launches": n_h,
+                    "pcie_gb_per_s": bytes_per_launch * n_h / dt_h / 1e9,
+                    "bytes_per_frame": bytes_per_launch // hb,
+                    "how": "BGRA + float32 depth from pinned host memory, double-buffered: the upload of the next "
+                           "launch overlaps the kernels of the current one",
+                    "pose_success_rate": float(hres["pnp_success"].mean())}
+        hctx.close()
+        del bufs, fp_, dp_
+
     # and on a flat wall (no depth relief at all): every PnP inlier set is planar, so the pose refinement starts from
     # a homography instead of the DLT
     flat = None
     if args.flat_scene:
-        fin = [build_inputs(S, F, seed=72000 + 1000 * rank + S * k, workers=render_workers, relief=0.0)
-               for k in range(NC)]
+        # the wall is seen at an angle: a camera that faces a wall squarely measures exactly equal depths, and an
+        # exactly coplanar 5-point sample has no EPnP solution (in OpenCV as little as here; real depth is never
+        # that flat)
+        fin = [build_inputs(S, F, seed=72000 + 1000 * rank + S * k, workers=render_workers, relief=0.0,
+                            tilt=(0.08, -0.05)) for k in range(NC)]
         ff = [torch.from_numpy(i[1]).cuda() for i in fin]
         fd_ = [torch.from_numpy(i[2]).cuda() for i in fin]
         for c in ctxs:
@@ -278,7 +331,7 @@ def main():
         steps_f = max(3, args.steps // 2)
         f_fps, f_dt, f_res, f_acc = measure(ff, fd_, steps_f, max(2, args.warmup), reps=3)
         flat = {"value": f_fps, "unit": "frames/s", "steps": steps_f, "ms_per_step": 1e3 * f_dt / steps_f,
-                "scene": "flat wall (relief 0), own texture per stream",
+                "scene": "flat wall seen at an angle (relief 0, slope 0.08 / -0.05), own texture per stream",
                 "stage_ms_per_launch": {k: round(v, 4) for k, v in f_acc.items()},
                 "mean_matches": float(f_res["n_matches"].mean()),
                 "pose_success_rate": float(f_res["pnp_success"].mean())}
@@ -370,6 +423,26 @@ def main():
             out["hard_scene"] = hard
         if flat is not None:
             out["flat_scene"] = flat
+        if host_fed is not None:
+            out["host_fed_fps"] = host_fed
+        if args.facade_latency and world == 1:
+            # the path the reference node takes: ONE stream, FrameProcessor::processFrame per frame through the C++
+            # facade (tools/facade_bench, its own process), host frames in, every result out by value
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import facade_latency
+                lat = {}
+                for det, pinned in (("fast", False), ("fast", True), ("orb", False)):
+                    r = facade_latency.run(iterations=200, detector=det, pinned=pinned)
+                    lat[f"{det}_{'pinned' if pinned else 'pageable'}"] = {
+                        "median_ms": r["median_ms"], "p90_ms": r["p90_ms"], "fps": r["fps"],
+                        "mean_keypoints": r["mean_keypoints"], "pose_rate": r["pose_rate"]}
+                lat["what"] = ("FrameProcessor::processFrame, one HD720 BGRA + float32 depth frame per call from host "
+                               "memory, median of 200 frames; fast = the reference's effective detector (FAST, 1000 "
+                               "key points), orb = DetectorMode::Orb with 2000 key points / 8 levels")
+                out["facade_latency_ms"] = lat
+            except Exception as e:  # the tool is optional for the throughput number
+                out["facade_latency_ms"] = {"error": str(e)[:200]}
         if world == 1 and args.cpu_frames > 0:
             cpu_fps = cpu_baseline(cam, frames_h[:F], depth_h[:F], args.cpu_frames, args.features, levels)
             if cpu_all is not None:

@@ -3,7 +3,9 @@
 // ONE camera stream, frames and depth handed over in ordinary host memory, every
 // result (key points, descriptors, matches, 3-D points, pose) returned by value.
 //
-// usage: facade_bench <dump> <width> <height> <channels> <n_frames> <fx> <fy> <cx> <cy> <iterations> [fast|orb]
+// usage: facade_bench <dump> <width> <height> <channels> <n_frames> <fx> <fy> <cx> <cy> <iterations> [fast|orb] [pinned]
+// pinned: the frames live in vo_host_alloc() memory, as a camera wrapper that clones into pinned buffers would
+// hand them over (default: ordinary pageable memory, like the cv::Mat clones of the reference node)
 // dump layout: n_frames x (H*W*C bytes), then n_frames x (H*W float32 depth in mm); the frames are
 // replayed cyclically (write a sequence whose last frame is one step from its first).
 // prints one JSON object: per-frame wall-clock milliseconds of processFrame.
@@ -30,12 +32,17 @@ int main(int argc, char **argv)
     const int iters = std::atoi(argv[10]);
     const bool orb = argc > 11 && std::strcmp(argv[11], "orb") == 0;
 
-    std::vector<uint8_t> frames((size_t)n * w * h * c);
-    std::vector<float> depth((size_t)n * w * h);
+    const bool pinned = argc > 12 && std::strcmp(argv[12], "pinned") == 0;
+    const size_t fbytes = (size_t)n * w * h * c, delems = (size_t)n * w * h;
+    std::vector<uint8_t> frames_v(pinned ? 0 : fbytes);
+    std::vector<float> depth_v(pinned ? 0 : delems);
+    uint8_t *frames = pinned ? static_cast<uint8_t *>(vo_host_alloc(fbytes)) : frames_v.data();
+    float *depth = pinned ? static_cast<float *>(vo_host_alloc(delems * sizeof(float))) : depth_v.data();
+    if (!frames || !depth) return 5;
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) return 3;
-    if (std::fread(frames.data(), 1, frames.size(), f) != frames.size()) return 4;
-    if (std::fread(depth.data(), sizeof(float), depth.size(), f) != depth.size()) return 4;
+    if (std::fread(frames, 1, fbytes, f) != fbytes) return 4;
+    if (std::fread(depth, sizeof(float), delems, f) != delems) return 4;
     std::fclose(f);
 
     auto detector = std::make_shared<vo::FeatureDetector>();
@@ -56,8 +63,8 @@ int main(int argc, char **argv)
     size_t kp = 0, matches = 0, poses = 0;
     for (int i = 0; i < iters + warm; i++) {
         const int k = i % n;
-        cv::Mat rgb(h, w, CV_MAKETYPE(CV_8U, c), frames.data() + (size_t)k * w * h * c);
-        cv::Mat dep(h, w, CV_32FC1, depth.data() + (size_t)k * w * h);
+        cv::Mat rgb(h, w, CV_MAKETYPE(CV_8U, c), frames + (size_t)k * w * h * c);
+        cv::Mat dep(h, w, CV_32FC1, depth + (size_t)k * w * h);
         const auto t0 = std::chrono::steady_clock::now();
         auto r = fp.processFrame(rgb, dep, cam, i == 0, true);
         const auto t1 = std::chrono::steady_clock::now();
@@ -73,9 +80,9 @@ int main(int argc, char **argv)
     for (double v : ms) sum += v;
     std::printf("{\"frames\": %d, \"median_ms\": %.4f, \"mean_ms\": %.4f, \"p90_ms\": %.4f, \"min_ms\": %.4f, "
                 "\"fps\": %.1f, \"mean_keypoints\": %.1f, \"mean_matches\": %.1f, \"pose_rate\": %.3f, "
-                "\"detector\": \"%s\"}\n",
+                "\"detector\": \"%s\", \"host_memory\": \"%s\"}\n",
                 iters, ms[ms.size() / 2], sum / ms.size(), ms[(size_t)(ms.size() * 0.9)], ms.front(),
                 1e3 * ms.size() / sum, (double)kp / iters, (double)matches / iters, (double)poses / iters,
-                orb ? "orb" : "fast");
+                orb ? "orb" : "fast", pinned ? "pinned" : "pageable");
     return 0;
 }

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(iterations=200, detector="fast", frames=8, seed=2000, timeout=300):
+def run(iterations=200, detector="fast", frames=8, seed=2000, timeout=300, pinned=False):
     from visual_odometry_amd import synth
     cam = synth.CONFIG_CAMERAS["hd720"]
     f, d, _ = synth.make_pingpong_batch(cam, 1, frames, seed, channels=4, relief=2.0)
@@ -24,7 +24,8 @@ def run(iterations=200, detector="fast", frames=8, seed=2000, timeout=300):
     try:
         out = subprocess.run([os.path.join(ROOT, "tools", "facade_bench"), path, str(cam.width), str(cam.height), "4",
                               str(frames), repr(cam.fx), repr(cam.fy), repr(cam.cx), repr(cam.cy), str(iterations),
-                              detector], capture_output=True, text=True, timeout=timeout)
+                              detector] + (["pinned"] if pinned else []), capture_output=True, text=True,
+                             timeout=timeout)
     finally:
         os.unlink(path)
     if out.returncode != 0:
@@ -33,4 +34,4 @@ def run(iterations=200, detector="fast", frames=8, seed=2000, timeout=300):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(detector=sys.argv[1] if len(sys.argv) > 1 else "fast")))
+    print(json.dumps(run(detector=sys.argv[1] if len(sys.argv) > 1 else "fast", pinned="pinned" in sys.argv[2:])))

@@ -59,8 +59,10 @@ class Scene:
 
     MM_PER_TEXEL = 4.0
 
-    def __init__(self, seed: int, extent_mm=(16000.0, 10000.0), n_shapes: int = 900, relief: float = 1.0):
+    def __init__(self, seed: int, extent_mm=(16000.0, 10000.0), n_shapes: int = 900, relief: float = 1.0,
+                 tilt=(0.0, 0.0)):
         self.relief = relief  # scales the height variation of the surface (1.0: +-1150 mm around 3.5 m)
+        self.tilt = tilt      # slope of the mean plane in u and v (0, 0: the camera's first pose faces it squarely)
         rng = np.random.default_rng(seed)
         tw = int(extent_mm[0] / self.MM_PER_TEXEL)
         th = int(extent_mm[1] / self.MM_PER_TEXEL)
@@ -86,8 +88,11 @@ class Scene:
         self.seed = seed
 
     def surface(self, u, v):
-        return 3500.0 + self.relief * (900.0 * np.sin(u / 1500.0) * np.cos(v / 1200.0)
-                                       + 250.0 * np.sin(u / 500.0 + v / 700.0))
+        z = 3500.0 + self.relief * (900.0 * np.sin(u / 1500.0) * np.cos(v / 1200.0)
+                                    + 250.0 * np.sin(u / 500.0 + v / 700.0))
+        if self.tilt[0] or self.tilt[1]:
+            z = z + self.tilt[0] * u + self.tilt[1] * v
+        return z
 
     def sample(self, u, v):
         tx = (u + self.extent[0] / 2) / self.MM_PER_TEXEL
@@ -193,17 +198,17 @@ def make_sequence(cam: Camera, n_frames: int, seed: int, channels: int = 4,
 
 
 def _stream_job(job):
-    cam, n_frames, seed, channels, relief, movers = job
-    seq = make_sequence(cam, n_frames, seed, channels, scene=Scene(seed, relief=relief), movers=movers)
+    cam, n_frames, seed, channels, relief, movers, tilt = job
+    seq = make_sequence(cam, n_frames, seed, channels, scene=Scene(seed, relief=relief, tilt=tilt), movers=movers)
     return seq["frames"], seq["depth"], seq["poses"]
 
 
 def make_streams(cam: Camera, n_streams: int, n_frames: int, seed: int, channels: int = 4, relief: float = 1.0,
-                 movers: int = 0, workers: int = 1):
+                 movers: int = 0, workers: int = 1, tilt=(0.0, 0.0)):
     """n_streams independent sequences (stream s: scene and noise of seed + s), rendered by `workers` processes.
     Returns a list of dicts like make_sequence's.  The workers are fresh interpreters (spawn), so this may be
     called from a process that already uses the GPU."""
-    jobs = [(cam, n_frames, seed + s, channels, relief, movers) for s in range(n_streams)]
+    jobs = [(cam, n_frames, seed + s, channels, relief, movers, tilt) for s in range(n_streams)]
     if workers > 1 and n_streams > 1:
         import concurrent.futures as cf
         import multiprocessing as mp
@@ -220,7 +225,7 @@ def pingpong(n):
 
 
 def make_pingpong_batch(cam: Camera, n_streams: int, frames_per_stream: int, seed: int, channels: int = 4,
-                        relief: float = 1.0, movers: int = 0, workers: int = 1):
+                        relief: float = 1.0, movers: int = 0, workers: int = 1, tilt=(0.0, 0.0)):
     """One launch of the batched pipeline: n_streams independent streams (seed + s), each walking forth and
     back over frames_per_stream / 2 + 1 rendered frames so that the launch can be repeated without a break in
     any stream.  Returns frames (S*F, H, W[, C]) and depth (S*F, H, W) in batch order (stream-major), and per
@@ -229,7 +234,7 @@ def make_pingpong_batch(cam: Camera, n_streams: int, frames_per_stream: int, see
     n_distinct = frames_per_stream // 2 + 1
     order = pingpong(n_distinct)
     assert len(order) == frames_per_stream
-    seqs = make_streams(cam, n_streams, n_distinct, seed, channels, relief, movers, workers)
+    seqs = make_streams(cam, n_streams, n_distinct, seed, channels, relief, movers, workers, tilt)
     frames = np.concatenate([q["frames"][order] for q in seqs])
     depth = np.concatenate([q["depth"][order] for q in seqs])
     truth = [[relative_pose(q["poses"][order[k - 1]], q["poses"][order[k]]) for k in range(frames_per_stream)]
