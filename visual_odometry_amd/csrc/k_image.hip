@@ -440,14 +440,13 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
 // x = b % 8 walks down whole tile columns (frame*tiles_x + tx) congruent to x
 // mod 8; vertically adjacent tiles, which share 8 of their 24 staged rows, are
 // then processed by the same L2 at about the same time.
+// (col = frame * tiles_x + tile column, ty = tile row: which tile this block processes)
 template <int CN>
-__global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
-                                                         int height, int src_stride,
-                                                         size_t src_frame_stride, PlaneBatch gray_out,
-                                                         PlaneBatch score, PlaneBatch blur, int thr,
-                                                         GrayCoeffs c, uint32_t *__restrict__ cand,
-                                                         uint32_t *__restrict__ tile_count, int batch,
-                                                         uint32_t inv_tiles_x, int margin)
+__device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int width, int height, int src_stride,
+                                        size_t src_frame_stride, PlaneBatch gray_out, PlaneBatch score,
+                                        PlaneBatch blur, int thr, GrayCoeffs c, uint32_t *__restrict__ cand,
+                                        uint32_t *__restrict__ tile_count, int batch, uint32_t inv_tiles_x,
+                                        int margin, int col, int ty)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
@@ -458,9 +457,6 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
-    // grid: x = 8 * tile row + XCD slot, y = group of eight tile columns (frame * tiles_x + tx)
-    const int xcd = blockIdx.x & 7;
-    const int col = blockIdx.y * 8 + xcd;
     // rows 16-B (BGRA) / 4-B (gray, BGR) aligned: vector loads allowed
     const bool aligned = CN == 4 ? ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 15) == 0)
                                  : ((((uintptr_t)src | (uintptr_t)src_stride | src_frame_stride) & 3) == 0);
@@ -468,7 +464,6 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     if (col >= batch * tiles_x) return;
     FeTile tile;
     {
-        const int ty = blockIdx.x >> 3;
         tile.frame = (int)__umulhi((uint32_t)col, inv_tiles_x);  // col / tiles_x (exact: host-side magic number)
         tile.x0 = (col - tile.frame * tiles_x) * FE_TW;
         tile.y0 = ty * FE_TH;
@@ -726,6 +721,55 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     FE_STAMP(9);
 }
 
+// grid: x = 8 * tile row + XCD slot, y = group of eight tile columns (frame * tiles_x + tx)
+template <int CN>
+__global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
+                                                         int height, int src_stride,
+                                                         size_t src_frame_stride, PlaneBatch gray_out,
+                                                         PlaneBatch score, PlaneBatch blur, int thr,
+                                                         GrayCoeffs c, uint32_t *__restrict__ cand,
+                                                         uint32_t *__restrict__ tile_count, int batch,
+                                                         uint32_t inv_tiles_x, int margin)
+{
+    fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
+                batch, inv_tiles_x, margin, (int)(blockIdx.y * 8 + (blockIdx.x & 7)), (int)(blockIdx.x >> 3));
+}
+
+// The tile kernel over several gray planes of different sizes in ONE launch (the upper levels of the ORB
+// pyramid): a 1-D grid, eight consecutive blocks (one per XCD) form a group, groups [first_group,
+// first_group + tiles_y * column groups) belong to a level, ordered column group major / tile row minor like the
+// 2-D grid above.  The levels are listed largest first, so the small ones fill the tail of the large ones instead
+// of each paying its own ramp-down.
+struct FeLevels {
+    int n;
+    struct L {
+        const uint8_t *src;
+        uint8_t *blur;
+        uint32_t *cand, *tile_count;
+        int width, height, pitch, tiles_y;
+        uint32_t inv_tiles_x, inv_tiles_y;
+        int first_group;
+    } lv[kOrbMaxLevels];
+    int total_groups;
+    size_t frame_stride;  // bytes between the planes of consecutive frames (same for input and output)
+};
+
+__global__ __launch_bounds__(FE_THREADS) void k_frontend_levels(FeLevels t, int thr, GrayCoeffs c, int batch, int margin)
+{
+    const int g = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kOrbMaxLevels; i++)
+        if (i < t.n && g >= t.lv[i].first_group) l = i;
+    const FeLevels::L &L = t.lv[l];
+    const int local = g - L.first_group;
+    const int cg = (int)__umulhi((uint32_t)local, L.inv_tiles_y);  // local / tiles_y
+    const int ty = local - cg * L.tiles_y;
+    fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
+               PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count, batch, L.inv_tiles_x, margin,
+               cg * 8 + xcd, ty);
+}
+
 #ifdef VO_FE_STAMPS
 extern "C" int vo_debug_fe_stamps(unsigned long long *out)
 {
@@ -754,6 +798,35 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
+}
+
+void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t *pyr, uint8_t *pyr_blur,
+                            uint32_t *cand, uint32_t *tile_count, int threshold, int batch, GrayCoeffs c,
+                            hipStream_t s, int margin)
+{
+    FeLevels t{};
+    t.frame_stride = plan.frame_bytes;
+    int groups = 0;
+    for (int l = first_level; l < plan.nlevels; l++) {
+        const OrbLevel &P = plan.lv[l];
+        FeLevels::L &L = t.lv[t.n++];
+        const int tiles_x = (P.w + FE_TW - 1) / FE_TW, tiles_y = (P.h + FE_TH - 1) / FE_TH;
+        L.src = pyr + P.off;
+        L.blur = pyr_blur + P.off;
+        L.cand = cand + P.cand_off;
+        L.tile_count = tile_count + P.count_off;
+        L.width = P.w; L.height = P.h; L.pitch = P.pitch; L.tiles_y = tiles_y;
+        L.inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
+        L.inv_tiles_y = (uint32_t)(0x100000000ull / (uint32_t)tiles_y) + 1u;
+        L.first_group = groups;
+        groups += tiles_y * ((tiles_x * batch + 7) / 8);
+    }
+    if (t.n == 0) return;
+    t.total_groups = groups;
+    threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
+    margin = margin < 3 ? 3 : margin;
+    hipLaunchKernelGGL(k_frontend_levels, dim3((unsigned)groups * 8u), dim3(FE_THREADS), 0, s, t, threshold, c, batch,
+                       margin);
 }
 
 // ---------------------------------------------------------------- select

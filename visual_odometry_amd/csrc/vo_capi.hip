@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -744,7 +745,13 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
         launch_resize_exact(level(d_pyr, l - 1), orb.lv[l - 1].w, orb.lv[l - 1].h, level(d_pyr, l), orb.lv[l].w,
                             orb.lv[l].h, d_orb_tab + orb.lv[l].xtab_off, d_orb_tab + orb.lv[l].ytab_off, batch, stream);
     mark(2);
-    for (int l = 1; l < orb.nlevels; l++) fast_level(l);
+    // levels 1 .. n-1 in one launch (VO_ORB_LEVEL_LAUNCHES=1: one launch per level, for A/B measurements)
+    static const bool per_level = [] { const char *e = getenv("VO_ORB_LEVEL_LAUNCHES"); return e && e[0] == '1'; }();
+    if (per_level)
+        for (int l = 1; l < orb.nlevels; l++) fast_level(l);
+    else
+        launch_frontend_levels(orb, 1, d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, fast_threshold, batch, gc,
+                               stream, kFBorder - 1);
     mark(3);
     launch_orb_select(orb, batch, d_pyr, d_orb_cand, d_orb_cand_count, d_orb_cand_flat, d_lvl_ras, d_lvl_resp,
                       d_lvl_n, stream);

@@ -100,6 +100,12 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
                      uint32_t *cand, uint32_t *tile_count, int batch,
                      GrayCoeffs c, hipStream_t s, int margin = 3);
 
+// launch_frontend for the gray planes of pyramid levels first_level .. nlevels-1 in one launch (input: the gray
+// pyramid, output: the blurred pyramid and the levels' corner lists, laid out as the plan says)
+void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t *pyr, uint8_t *pyr_blur,
+                            uint32_t *cand, uint32_t *tile_count, int threshold, int batch, GrayCoeffs c,
+                            hipStream_t s, int margin);
+
 // Keep the max_features best keys per frame (all of them, in raster order,
 // when there are not more than max_features), drop keypoints closer than
 // `border` px to the image edge, write vo_kp records.  cand/tile_count as
