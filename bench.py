@@ -34,15 +34,16 @@ HARD_SCENE_MOVERS = 30       # independently moving rectangles of the hard scene
                              # survivors then violate the camera's epipolar geometry)
 
 
-def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0, tilt=(0.0, 0.0)):
+def build_inputs(streams, frames, seed, movers=0, workers=1, relief=2.0, tilt=(0.0, 0.0), cam_name="hd720",
+                 channels=4):
     """`streams` independent HD720 BGRA + depth streams (stream s is rendered from seed + s: its own scene,
     texture and noise), `frames` consecutive frames each, walking forth and back over frames/2 + 1 camera
     positions so that a launch can be repeated.  Returns the camera, the frames and depth planes in batch order
     and, per stream, the ground-truth T_prev_from_curr of each frame."""
     from visual_odometry_amd import synth
-    cam = synth.CONFIG_CAMERAS["hd720"]
-    f, d, truth = synth.make_pingpong_batch(cam, streams, frames, seed, channels=4, relief=relief, movers=movers,
-                                            workers=workers, tilt=tilt)
+    cam = synth.CONFIG_CAMERAS[cam_name]
+    f, d, truth = synth.make_pingpong_batch(cam, streams, frames, seed, channels=channels, relief=relief,
+                                            movers=movers, workers=workers, tilt=tilt)
     return cam, f, d, truth
 
 
@@ -139,6 +140,10 @@ def main():
                     help="also run the same launch on streams with independently moving objects (0 = skip)")
     ap.add_argument("--flat-scene", type=int, default=1,
                     help="also run the same launch on streams that look at a flat wall (0 = skip)")
+    ap.add_argument("--config", choices=("hd720", "kitti8"), default="hd720",
+                    help="hd720: the headline workload, the same number of streams on every GPU (weak scaling); "
+                         "kitti8: eight KITTI-shaped 1241x376 BGR streams in total, dealt round-robin to the ranks "
+                         "(strong scaling: 8, 4, 2, 1 streams per GPU at 1, 2, 4, 8 GPUs)")
     ap.add_argument("--host-fed", type=int, default=1, help="also measure the host-fed (PCIe-inclusive) rate (0 = skip)")
     ap.add_argument("--facade-latency", type=int, default=1,
                     help="also measure the single-stream latency through the C++ facade (0 = skip)")
@@ -171,16 +176,33 @@ def main():
 
     from visual_odometry_amd import capi
 
-    NC = max(1, args.contexts)
+    from visual_odometry_amd import shard
+    kitti = args.config == "kitti8"
+    NC = max(1, args.contexts) if not kitti else 1
     assert args.streams % NC == 0, "--streams must be a multiple of --contexts"
-    S, F = args.streams // NC, args.frames   # streams per context
+    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1))
+    if kitti:
+        # configs[3]: eight streams in all; rank r owns streams r, r + world, ... and renders exactly those (a stream's
+        # seed does not depend on the number of ranks)
+        if world > 8:
+            raise SystemExit("--config kitti8 has eight streams: at most eight ranks")
+        args.hard_scene = args.flat_scene = args.host_fed = args.facade_latency = 0
+        args.cpu_frames = 0
+        mine = shard.stream_seeds(8, world, rank, base_seed=4000)
+        owned = shard.gather_stream_ids([s for s, _ in mine], dist)
+        assert sorted(owned) == list(range(8)), "every stream is owned exactly once"
+        S, F, C = len(mine), args.frames, 3
+        parts = [build_inputs(1, F, seed=sd, cam_name="kitti", channels=3) for _, sd in mine]
+        inputs = [(parts[0][0], np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]),
+                   [p[3][0] for p in parts])]
+    else:
+        S, F, C = args.streams // NC, args.frames, 4   # streams per context
+        # every stream of every context and rank has its own seed: 2000 + 1000 * rank + stream
+        inputs = [build_inputs(S, F, seed=2000 + 1000 * rank + S * k, workers=render_workers) for k in range(NC)]
     Bc = S * F                               # frames per context per step
     B = Bc * NC                              # frames per step per GPU
-    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1))
-    # every stream of every context and rank has its own seed: 2000 + 1000 * rank + stream
-    inputs = [build_inputs(S, F, seed=2000 + 1000 * rank + S * k, workers=render_workers) for k in range(NC)]
     cam, frames_h, depth_h, truth = inputs[0]
-    H, W, C = cam.height, cam.width, 4
+    H, W = cam.height, cam.width
     K = (cam.fx, cam.fy, cam.cx, cam.cy)
     frames_d = [torch.from_numpy(i[1]).cuda() for i in inputs]
     depth_d = [torch.from_numpy(i[2]).cuda() for i in inputs]
@@ -201,8 +223,6 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-
-    from visual_odometry_amd import shard
 
     def measure(fds, dds, steps, warmup, reps=5):
         """warmup + exactly `steps` timed steps over the given device frames (one tensor per context), then the
@@ -394,16 +414,20 @@ def main():
                     stage_roof[k]["algorithmic_bytes"] = amount * 1e9
                     stage_roof[k]["traffic"] = measured.get(k)
         out = {
-            "metric": "frames/sec (detect+match+RANSAC pose) @1280x720, 2000 kp",
+            "metric": "frames/sec (detect+match+RANSAC pose) @1280x720, 2000 kp" if not kitti else
+                      "frames/sec (detect+match+RANSAC pose) @1241x376 BGR, 2000 kp, 8 streams in total",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if kitti else "weak",
             "vs_baseline": None, "dtype": "u8/int32 (image), %s (match), f32 (Harris, angle), f64 (RANSAC)" %
                      ("int8 MFMA -> int32" if args.matcher == "mfma" else "u32 xor/popcount"),
             "data": "synthetic",
-            "config": {"workload": "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp" %
+            "config": {"workload": ("kitti_1241x376_bgr_8_streams_total_2000kp_%s_ratio_Fransac_pnp" if kitti else
+                                    "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp") %
                                    ("orb8level" if levels else "fast1level"),
                        "detector": args.detector, "matcher": args.matcher, "pyramid_levels": levels or 1,
-                       "streams_per_gpu": S * NC, "distinct_streams": True, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
+                       "streams_per_gpu": S * NC, "streams_total": 8 if kitti else S * NC * world,
+                       "distinct_streams": True, "contexts_per_gpu": NC, "frames_per_stream_per_step": F,
                        "frames_per_step": B, "frames_per_launch": Bc,
                        "max_features": args.features, "fast_threshold": 20,
                        "parallelism": "independent streams, one process per GPU, no collective"},

@@ -17,6 +17,21 @@ def streams_of_rank(n_streams: int, world: int, rank: int) -> list[int]:
     return list(range(rank, n_streams, world))
 
 
+def stream_seeds(n_streams: int, world: int, rank: int, base_seed: int) -> list[tuple[int, int]]:
+    """(global stream id, scene seed) of every stream `rank` owns.  A stream keeps its seed -- hence its frames --
+    whatever the number of ranks, so runs on 1, 2, 4 and 8 GPUs process the same job (strong scaling)."""
+    return [(s, base_seed + s) for s in streams_of_rank(n_streams, world, rank)]
+
+
+def gather_stream_ids(ids: list[int], dist=None) -> list[int]:
+    """All ranks' stream ids, concatenated in rank order (identity when not distributed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(ids)
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, list(ids))
+    return [s for part in out for s in part]
+
+
 def max_over_ranks(value: float, dist=None, device=None) -> float:
     """MAX all-reduce of a scalar (identity when not distributed)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
