@@ -191,6 +191,51 @@ static void svd12_onesided(const double *Gcm, int rows, double *w, double *Vt)
     }
 }
 
+/* Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite 12 x 12 matrix (row-major)
+ * by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
+ * the pose refinement has one eigenvalue far below the others (the solution, at the noise level), so the
+ * iteration converges in a few steps; what cv::SVD would return as the last row of V^T, up to sign. */
+static void smallest_eigvec12(const double *A, double *x)
+{
+    /* L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
+     * number: for inverse iteration that only steepens the amplification of the wanted direction */
+    double Lf[144], D[12];
+    double dmax = 0;
+    for (int i = 0; i < 12; i++) dmax = fmax(dmax, fabs(A[i * 12 + i]));
+    const double tiny = dmax * 1e-30 + 1e-300;
+    for (int j = 0; j < 12; j++) {
+        double d = A[j * 12 + j];
+        for (int k = 0; k < j; k++) d -= Lf[j * 12 + k] * Lf[j * 12 + k] * D[k];
+        if (!(d > tiny)) d = tiny;
+        D[j] = d;
+        for (int i = j + 1; i < 12; i++) {
+            double v = A[i * 12 + j];
+            for (int k = 0; k < j; k++) v -= Lf[i * 12 + k] * Lf[j * 12 + k] * D[k];
+            Lf[i * 12 + j] = v / d;
+        }
+    }
+    for (int i = 0; i < 12; i++) x[i] = 1.0 / sqrt(12.0);
+    for (int it = 0; it < 12; it++) {
+        double y[12];
+        for (int i = 0; i < 12; i++) {          /* L z = x */
+            double v = x[i];
+            for (int k = 0; k < i; k++) v -= Lf[i * 12 + k] * y[k];
+            y[i] = v;
+        }
+        for (int i = 0; i < 12; i++) y[i] /= D[i];
+        for (int i = 11; i >= 0; i--) {         /* L^T y = z */
+            double v = y[i];
+            for (int k = i + 1; k < 12; k++) v -= Lf[k * 12 + i] * y[k];
+            y[i] = v;
+        }
+        double nrm = 0;
+        for (int i = 0; i < 12; i++) nrm += y[i] * y[i];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0) || !isfinite(nrm)) break;
+        for (int i = 0; i < 12; i++) x[i] = y[i] / nrm;
+    }
+}
+
 /* nearest rotation to a 3x3 matrix A (U V^T of its SVD), via the
  * eigen-decomposition of A^T A; a vanishing third singular value is
  * completed with a cross product. */
@@ -892,7 +937,7 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
     } else {
     if (n < 6) return 0; /* "DLT algorithm needs at least 6 points" */
     /* DLT on normalised image points */
-    double LL[144] = {0}, LW[12], LV[144];
+    double LL[144] = {0};
     for (int i = 0; i < n; i++) {
         const double *M = obj + 3 * i;
         double x = -(img[2 * i] - cx) / fx, y = -(img[2 * i + 1] - cy) / fy;
@@ -901,14 +946,8 @@ int ora_pnp_iterative(const double *obj, const double *img, int n, double fx, do
         for (int a = 0; a < 12; a++)
             for (int b = 0; b < 12; b++) LL[a * 12 + b] += r0[a] * r0[b] + r1[a] * r1[b];
     }
-    {
-        double llcm[144];
-        for (int a = 0; a < 12; a++)
-            for (int b = 0; b < 12; b++) llcm[12 * b + a] = LL[a * 12 + b];
-        svd12_onesided(llcm, 12, LW, LV);
-    }
     double RRt[12];
-    memcpy(RRt, LV + 11 * 12, sizeof(RRt));
+    smallest_eigvec12(LL, RRt);
     double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
     double tt[3] = {RRt[3], RRt[7], RRt[11]};
     double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +

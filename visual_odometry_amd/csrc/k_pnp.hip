@@ -735,17 +735,42 @@ __device__ __forceinline__ float pnp_error(const float *o, const float *im, cons
     return (float)((double)dx * dx + (double)dy * dy);
 }
 
-// block-wide deterministic sum of NV per-thread doubles -> S.sums[0..NV)
+// block-wide deterministic sum of NV per-thread doubles -> S.sums[0..NV).
+// Inside a wave the values are reduced "reduce-scatter" style: at every step a lane hands half of the values it
+// still holds to its partner and adds the partner's other half, so the exchange volume halves each step (V - 1
+// + log2(64 / V) shuffles for V = NV rounded up to a power of two, against 6 * NV for value-by-value trees).
+// The pairing is fixed, hence the sums are bitwise reproducible.
 template <int NV>
 __device__ void block_reduce(PrShared &S, double (&v)[NV])
 {
+    constexpr int V = NV <= 1 ? 1 : NV <= 2 ? 2 : NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+    static_assert(NV <= 64 && NV <= PR_NRED, "at most one value per lane at the end, and room in the LDS staging");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[V];
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        double x = v[k];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (lane == 0) S.red[wave][k] = x;
+    for (int k = 0; k < V; k++) a[k] = k < NV ? v[k] : 0.0;
+    int idx = 0;        // index of the value this lane ends up with
+    int plain = 0;      // lane bits over which the final value was summed by plain exchanges
+#pragma unroll
+    for (int step = 0; step < 6; step++) {
+        const int off = 32 >> step;
+        const int cnt = (V >> step) > 0 ? (V >> step) : 1;  // values held before this step
+        const bool up = (lane & off) != 0;
+        if (cnt > 1) {
+            const int h = cnt / 2;
+#pragma unroll
+            for (int i = 0; i < h; i++) {
+                const double send = up ? a[i] : a[i + h];
+                const double keep = up ? a[i + h] : a[i];
+                a[i] = keep + __shfl_xor(send, off);
+            }
+            idx += up ? h : 0;
+        } else {
+            a[0] += __shfl_xor(a[0], off);
+            plain |= off;
+        }
     }
+    if ((lane & plain) == 0 && idx < NV) S.red[wave][idx] = a[0];
     __syncthreads();
     if ((int)threadIdx.x < NV) {
         double x = 0;
@@ -808,6 +833,51 @@ __device__ __noinline__ void eig9_smallest(const double *Ain, double *vec)
             if (A[order[j] * N + order[j]] > A[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     const int m = order[N - 1];
     for (int k = 0; k < N; k++) vec[k] = V[k * N + m];
+}
+
+// Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite 12 x 12 matrix (row-major)
+// by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
+// the pose refinement has one eigenvalue far below the others (the solution, at the noise level), so the
+// iteration converges in a few steps.  One lane; a tenth of the cycles of a 12-column Jacobi decomposition.
+__device__ __noinline__ void smallest_eigvec12(const double *A, double *x)
+{
+    // L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
+    // number: for inverse iteration that only steepens the amplification of the wanted direction
+    double Lf[144], D[12];
+    double dmax = 0;
+    for (int i = 0; i < 12; i++) dmax = fmax(dmax, fabs(A[i * 12 + i]));
+    const double tiny = dmax * 1e-30 + 1e-300;
+    for (int j = 0; j < 12; j++) {
+        double d = A[j * 12 + j];
+        for (int k = 0; k < j; k++) d -= Lf[j * 12 + k] * Lf[j * 12 + k] * D[k];
+        if (!(d > tiny)) d = tiny;
+        D[j] = d;
+        for (int i = j + 1; i < 12; i++) {
+            double v = A[i * 12 + j];
+            for (int k = 0; k < j; k++) v -= Lf[i * 12 + k] * Lf[j * 12 + k] * D[k];
+            Lf[i * 12 + j] = v / d;
+        }
+    }
+    for (int i = 0; i < 12; i++) x[i] = 1.0 / sqrt(12.0);
+    for (int it = 0; it < 12; it++) {
+        double y[12];
+        for (int i = 0; i < 12; i++) {          // L z = x
+            double v = x[i];
+            for (int k = 0; k < i; k++) v -= Lf[i * 12 + k] * y[k];
+            y[i] = v;
+        }
+        for (int i = 0; i < 12; i++) y[i] /= D[i];
+        for (int i = 11; i >= 0; i--) {         // L^T y = z
+            double v = y[i];
+            for (int k = i + 1; k < 12; k++) v -= Lf[k * 12 + i] * y[k];
+            y[i] = v;
+        }
+        double nrm = 0;
+        for (int i = 0; i < 12; i++) nrm += y[i] * y[i];
+        nrm = sqrt(nrm);
+        if (!(nrm > 0) || !isfinite(nrm)) break;
+        for (int i = 0; i < 12; i++) x[i] = y[i] / nrm;
+    }
 }
 
 // 8x8 solve, Gaussian elimination with partial pivoting; false when singular
@@ -1601,34 +1671,23 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         }
         block_reduce<40>(S, acc);
         PNP_STAMP(7);
-        // (if the decomposition below breaks down in NaNs no lane owns the smallest singular value: the zero
-        // vector then fails the scale test instead of stale memory seeding the refinement)
-        if (tid < 12) S.null12[tid] = 0;
-        __syncthreads();
-        if (wave == 0) {
-            // column gl of the symmetric 12 x 12 matrix, then its singular vectors
-            const int gl = lane & (PR_GROUP - 1);
-            double g[12], v[12];
-#pragma unroll
-            for (int row = 0; row < 12; row++) {
-                double val = 0;
-                if (gl < 12 && lane < PR_GROUP) {
-                    const int br = row >> 2, bc = gl >> 2, a = row & 3, c2 = gl & 3;
+        if (tid == 0) {
+            // the symmetric 12 x 12 matrix from its blocks, then the eigenvector of its smallest eigenvalue
+            double LL[144];
+            for (int row = 0; row < 12; row++)
+                for (int cc = 0; cc < 12; cc++) {
+                    const int br = row >> 2, bc = cc >> 2, a = row & 3, c2 = cc & 3;
                     const int lo = a < c2 ? a : c2, hi = a < c2 ? c2 : a;
                     const int q = lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo);  // index in the upper triangle of a 4x4
+                    double val = 0;
                     if (br == bc) val = (br == 2) ? S.sums[30 + q] : S.sums[q];
-                    else if (br + bc == 2 && br != bc) val = S.sums[10 + q];  // blocks (0,2), (2,0)
-                    else if (br + bc == 3) val = S.sums[20 + q];              // blocks (1,2), (2,1)
+                    else if (br + bc == 2) val = S.sums[10 + q];  // blocks (0,2), (2,0)
+                    else if (br + bc == 3) val = S.sums[20 + q];  // blocks (1,2), (2,1)
+                    LL[row * 12 + cc] = val;
                 }
-                g[row] = val;
-            }
-            double n2;
-            int rank;
-            group_svd12<12>(g, v, gl, &n2, &rank);
-            if (lane < 12 && rank == 11) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) S.null12[i] = v[i];
-            }
+            double v[12];
+            smallest_eigvec12(LL, v);
+            for (int i = 0; i < 12; i++) S.null12[i] = v[i];
         }
         __syncthreads();
         PNP_STAMP(8);
@@ -1669,10 +1728,11 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         double prevErrNorm = DBL_MAX, errNorm = 0;
         int lambdaLg10 = -3, iters = 0;
         for (;;) {
-            // J^T J, J^T e, |e|^2 at S.param
-            double acc[PR_NRED];
+            // J^T J (upper triangle), J^T e, |e|^2 at S.param
+            constexpr int NLM = 21 + 6 + 1;
+            double acc[NLM];
 #pragma unroll
-            for (int j = 0; j < PR_NRED; j++) acc[j] = 0;
+            for (int j = 0; j < NLM; j++) acc[j] = 0;
             {
                 double R[9], dRdr[27], p[6];
                 for (int j = 0; j < 6; j++) p[j] = S.param[j];
@@ -1698,23 +1758,29 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
                         j0[q] = fx * (dX - x * dZ) * z;
                         j1[q] = fy * (dY - y * dZ) * z;
                     }
+                    int q = 0;
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
 #pragma unroll
-                        for (int bb = 0; bb < 6; bb++) acc[a * 6 + bb] += j0[a] * j0[bb] + j1[a] * j1[bb];
-                        acc[36 + a] += j0[a] * e0 + j1[a] * e1;
+                        for (int bb = a; bb < 6; bb++, q++) acc[q] += j0[a] * j0[bb] + j1[a] * j1[bb];
+                        acc[21 + a] += j0[a] * e0 + j1[a] * e1;
                     }
-                    acc[42] += e0 * e0 + e1 * e1;
+                    acc[27] += e0 * e0 + e1 * e1;
                 }
             }
-            block_reduce<PR_NRED>(S, acc);
+            block_reduce<NLM>(S, acc);
             if (tid < 6) S.prev[tid] = S.param[tid];
-            if (iters == 0) prevErrNorm = sqrt(S.sums[42]);
+            if (iters == 0) prevErrNorm = sqrt(S.sums[27]);
             double JtJ[36], JtErr[6];
+            {
+                int q = 0;
 #pragma unroll
-            for (int j = 0; j < 36; j++) JtJ[j] = S.sums[j];
+                for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int j = 0; j < 6; j++) JtErr[j] = S.sums[36 + j];
+                    for (int bb = a; bb < 6; bb++, q++) JtJ[a * 6 + bb] = JtJ[bb * 6 + a] = S.sums[q];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) JtErr[j] = S.sums[21 + j];
             __syncthreads();
             for (;;) {
                 if (tid == 0) {
