@@ -3,15 +3,51 @@
 // raw frame dump written by tests/test_gpu_facade.py, and prints the results
 // for the Python side to compare with the oracle.
 //
-// usage: facade_test <dump> <width> <height> <channels> <n_frames> <fx> <fy> <cx> <cy> [imu_tx_mm]
+// usage: facade_test <dump> <width> <height> <channels> <n_frames> <fx> <fy> <cx> <cy> [imu_tx_mm|-] [fast|orb] [out]
+// With `out`, everything that crosses the class boundary is written there in binary, per processFrame call and
+// for the standalone detectFeatures / match calls: key points (all seven cv::KeyPoint fields), descriptor rows,
+// DMatch records with both point lists, the 3-D points.
 // dump layout: n_frames x (H*W*C bytes), then n_frames x (H*W float32 depth)
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "visual_odometry/frame_processor.hpp"
 #include "visual_odometry/image_processor.hpp"
+
+static FILE *g_out = nullptr;
+
+static void put_i32(int v) { if (g_out) std::fwrite(&v, 4, 1, g_out); }
+static void put_f32(float v) { if (g_out) std::fwrite(&v, 4, 1, g_out); }
+
+static void dump_features(const vo::Features &f)
+{
+    if (!g_out) return;
+    put_i32((int)f.keypoints.size());
+    for (const cv::KeyPoint &k : f.keypoints) {
+        put_f32(k.pt.x); put_f32(k.pt.y); put_f32(k.size); put_f32(k.angle); put_f32(k.response);
+        put_i32(k.octave); put_i32(k.class_id);
+    }
+    put_i32(f.descriptors.rows);
+    put_i32(f.descriptors.cols);
+    for (int i = 0; i < f.descriptors.rows; i++) std::fwrite(f.descriptors.ptr<uint8_t>(i), 1, (size_t)f.descriptors.cols, g_out);
+}
+
+static void dump_matches(const vo::FeatureMatches &m)
+{
+    if (!g_out) return;
+    put_i32((int)m.matches.size());
+    for (size_t i = 0; i < m.matches.size(); i++) {
+        put_i32(m.matches[i].queryIdx); put_i32(m.matches[i].trainIdx); put_i32(m.matches[i].imgIdx);
+        put_f32(m.matches[i].distance);
+        put_f32(m.prev_points[i].x); put_f32(m.prev_points[i].y);
+        put_f32(m.curr_points[i].x); put_f32(m.curr_points[i].y);
+    }
+    put_i32((int)m.prev_points_3d.size());
+    for (const cv::Point3f &p : m.prev_points_3d) { put_f32(p.x); put_f32(p.y); put_f32(p.z); }
+}
 
 static unsigned long long fnv1a(const cv::Mat &m)
 {
@@ -29,8 +65,10 @@ int main(int argc, char **argv)
     vo::CameraParams cam;
     cam.fx = std::atof(argv[6]); cam.fy = std::atof(argv[7]); cam.cx = std::atof(argv[8]); cam.cy = std::atof(argv[9]);
     cam.width = w; cam.height = h;
-    const bool use_imu = argc > 10;
+    const bool use_imu = argc > 10 && std::string(argv[10]) != "-";
     const double imu_tx = use_imu ? std::atof(argv[10]) : 0.0;
+    const bool orb = argc > 11 && std::string(argv[11]) == "orb";
+    if (argc > 12) g_out = std::fopen(argv[12], "wb");
 
     std::vector<uint8_t> frames((size_t)n * w * h * c);
     std::vector<float> depth((size_t)n * w * h);
@@ -46,6 +84,9 @@ int main(int argc, char **argv)
     detector->setScaleFactor(1.2f);
     detector->setNLevels(8);
     detector->setVisualizationType("rich");
+    // opt-in: the three setters above take effect (full ORB detector); default: the reference's effective
+    // FAST + ORB::compute with 1000 / 20, whatever the setters said
+    if (orb) detector->setDetectorMode(vo::DetectorMode::Orb);
     vo::FrameProcessor fp(detector, matcher);
 
     vo::Features prev_feat;
@@ -61,6 +102,8 @@ int main(int argc, char **argv)
             imu.angular_rate = 0.0;
         }
         auto r = fp.processFrame(rgb, dep, cam, i == 0, true, imu);
+        dump_features(r.features);
+        dump_matches(r.matches);
         std::printf("frame %d kp %zu matches %zu p3d %zu pnp %d inl %d tot %d", i, r.features.keypoints.size(),
                     r.matches.size(), r.matches.prev_points_3d.size(), (int)r.pnp_success, r.pnp_inliers,
                     r.pnp_total_matches);
@@ -79,6 +122,8 @@ int main(int argc, char **argv)
             vo::Features cur = detector->detectFeatures(bgr);  // defaults 1000 / 20
             vo::FeatureMatches m = matcher->match(prev_feat, cur, cv::Mat(), cv::Mat());
             std::printf("ops kp %zu desc_rows %d matches %zu\n", cur.keypoints.size(), cur.descriptors.rows, m.size());
+            dump_features(cur);
+            dump_matches(m);
         }
         if (i == 0) {
             cv::Mat bgr(h, w, CV_8UC3);
@@ -86,6 +131,7 @@ int main(int argc, char **argv)
                 for (int x = 0; x < w; x++)
                     for (int k = 0; k < 3; k++) bgr.ptr<uint8_t>(y)[3 * x + k] = rgb.ptr<uint8_t>(y)[c * x + k];
             prev_feat = detector->detectFeatures(bgr);
+            dump_features(prev_feat);
 
             // ImageProcessor as declared in vo_node.hpp:56 (defaults, then histogram equalisation + 5x5)
             vo::ImageProcessor ip;
@@ -121,5 +167,6 @@ int main(int argc, char **argv)
     } catch (const std::exception &e) {
         std::printf("gray_process threw\n");
     }
+    if (g_out) std::fclose(g_out);
     return 0;
 }

@@ -16,20 +16,119 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "facade_test")
 
 
-def _run(seq, cam, extra=()):
+def _run(seq, cam, extra=(), dump=False):
     assert os.path.exists(BIN), "build tests/cpp/facade_test with __graft_entry__.build()"
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
         f.write(np.ascontiguousarray(seq["frames"]).tobytes())
         f.write(np.ascontiguousarray(seq["depth"], np.float32).tobytes())
         path = f.name
+    blob = None
     try:
         n, h, w, c = seq["frames"].shape
+        args = list(extra)
+        if dump:
+            args = (args + ["-", "fast"])[:2] + [path + ".out"]
         out = subprocess.run([BIN, path, str(w), str(h), str(c), str(n), repr(cam.fx), repr(cam.fy), repr(cam.cx),
-                              repr(cam.cy), *extra], capture_output=True, text=True, timeout=120)
+                              repr(cam.cy), *args], capture_output=True, text=True, timeout=120)
+        if dump and os.path.exists(path + ".out"):
+            blob = open(path + ".out", "rb").read()
+            os.unlink(path + ".out")
     finally:
         os.unlink(path)
     assert out.returncode == 0, out.stderr
-    return out.stdout.splitlines(), out.stderr
+    return (out.stdout.splitlines(), out.stderr, blob) if dump else (out.stdout.splitlines(), out.stderr)
+
+
+CVKP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                 ("octave", "<i4"), ("class_id", "<i4")])
+CVMATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4"),
+                    ("px", "<f4"), ("py", "<f4"), ("cx", "<f4"), ("cy", "<f4")])
+
+
+class _Reader:
+    """The binary record stream facade_test writes."""
+
+    def __init__(self, blob):
+        self.b, self.o = blob, 0
+
+    def _take(self, dtype, n):
+        a = np.frombuffer(self.b, dtype, n, self.o)
+        self.o += a.nbytes
+        return a
+
+    def features(self):
+        k = self._take(CVKP, int(self._take("<i4", 1)[0]))
+        rows, cols = (int(v) for v in self._take("<i4", 2))
+        return k, self._take(np.uint8, rows * cols).reshape(rows, cols)
+
+    def matches(self):
+        m = self._take(CVMATCH, int(self._take("<i4", 1)[0]))
+        return m, self._take("<f4", 3 * int(self._take("<i4", 1)[0])).reshape(-1, 3)
+
+
+def _same_features(got, ref_k, ref_d):
+    k, d = got
+    assert len(k) == len(ref_k) and d.shape == ((len(ref_k), 32) if len(ref_k) else (0, 0))
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(k[f], ref_k[f]), f
+    assert (k["class_id"] == -1).all()              # cv::KeyPoint's default
+    if len(ref_k):
+        assert np.array_equal(d, ref_d)
+
+
+def _same_matches(got, ref_m, ref_p3=None):
+    m, p3 = got
+    assert len(m) == len(ref_m)
+    assert np.array_equal(m["queryIdx"], ref_m["query"]) and np.array_equal(m["trainIdx"], ref_m["train"])
+    assert (m["imgIdx"] == 0).all() and np.array_equal(m["distance"], ref_m["distance"])
+    for f in ("px", "py", "cx", "cy"):
+        assert np.array_equal(m[f], ref_m[f]), f
+    if ref_p3 is not None:
+        assert np.array_equal(p3, ref_p3)
+
+
+@pytest.mark.parametrize("mode", ["fast", "orb"])
+def test_facade_outputs_match_oracle_content(oracle, mode):
+    """Everything that crosses the class boundary, element by element: key points (all cv::KeyPoint fields),
+    descriptor rows, DMatch records, both point lists and the 3-D points of FrameProcessor::processFrame, and
+    the standalone FeatureDetector::detectFeatures / FeatureMatcher::match -- in the default mode (FAST +
+    ORB::compute, 1000 / 20, as the reference executes) and with the detector switched to the full ORB detector
+    its setters describe (2000 key points, 1.2, 8 levels)."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    seq = synth.make_sequence(cam, 3, seed=717, channels=4)
+    lines, err, blob = _run(seq, cam, ("-", mode), dump=True)
+    assert blob
+    rd = _Reader(blob)
+    orb = mode == "orb"
+    ref = OracleStream(K, 2000, 20, orb_levels=8, feature_cap=2064) if orb else OracleStream(K, 1000, 20)
+
+    def detect_bgr(i):
+        g = oracle.gray(seq["frames"][i][..., :3])
+        if orb:
+            k, d = oracle.orb_detect(g, 2000, 1.2, 8, 20)
+            return k[:2064], d[:2064]
+        return oracle.detect(g, 1000, 20)
+
+    n_pose = 0
+    for i in range(3):
+        r = ref.process(seq["frames"][i], seq["depth"][i])
+        _same_features(rd.features(), r["kps"], r["desc"])
+        exp = r["valid"] if len(r["valid"]) else r["tracked"]
+        _same_matches(rd.matches(), exp, r["pts3"])
+        n_pose += int(r["pnp_success"])
+        if orb and i == 0:
+            assert len(np.unique(r["kps"]["octave"])) == 8 and len(r["kps"]) >= 1900
+        if i == 0:
+            k0, d0 = detect_bgr(0)
+            _same_features(rd.features(), k0, d0)                  # detectFeatures(bgr) of frame 0
+        if i == 1:
+            k1, d1 = detect_bgr(1)
+            _same_features(rd.features(), k1, d1)                  # detectFeatures(bgr) of frame 1
+            m, _, _ = oracle.match_filter(oracle.knn2(d0, d1), len(k1), k0, k1, 0.7)
+            _same_matches(rd.matches(), m)                         # match(prev, cur)
+    assert rd.o == len(blob) and n_pose == 2
 
 
 def _parse_frame(line):
