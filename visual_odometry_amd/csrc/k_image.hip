@@ -5,6 +5,8 @@
 //
 // All arithmetic here is 8/16/32-bit integer and bit-exact by construction;
 // the work is HBM/LDS/VALU integer work, there is nothing MFMA-shaped.
+#include <stdlib.h>
+
 #include "vo_internal.h"
 
 namespace vo {
@@ -729,10 +731,21 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
                                                          uint32_t *__restrict__ tile_count, int batch,
-                                                         uint32_t inv_tiles_x, int margin)
+                                                         uint32_t inv_tiles_x, int margin, uint32_t inv_tiles_y)
 {
+    if (inv_tiles_y == 0) {
+        fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
+                    batch, inv_tiles_x, margin, (int)(blockIdx.y * 8 + (blockIdx.x & 7)), (int)(blockIdx.x >> 3));
+        return;
+    }
+    // row-major variant: grid x = 8 * tile column + XCD slot, y = group of eight tile rows (frame * tiles_y + ty);
+    // the tiles of one tile row run on one XCD, one after the other
+    const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
+    const int row = (int)(blockIdx.y * 8 + (blockIdx.x & 7));
+    if (row >= batch * tiles_y) return;
+    const int frame = (int)__umulhi((uint32_t)row, inv_tiles_y);
     fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
-                batch, inv_tiles_x, margin, (int)(blockIdx.y * 8 + (blockIdx.x & 7)), (int)(blockIdx.x >> 3));
+                batch, inv_tiles_x, margin, frame * tiles_x + (int)(blockIdx.x >> 3), row - frame * tiles_y);
 }
 
 // The tile kernel over several gray planes of different sizes in ONE launch (the upper levels of the ORB
@@ -751,6 +764,7 @@ struct FeLevels {
         int first_group;
     } lv[kOrbMaxLevels];
     int total_groups;
+    int by_rows;          // groups enumerate (tile-row group, tile column) instead of (tile-column group, tile row)
     size_t frame_stride;  // bytes between the planes of consecutive frames (same for input and output)
 };
 
@@ -763,6 +777,17 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_levels(FeLevels t, int 
         if (i < t.n && g >= t.lv[i].first_group) l = i;
     const FeLevels::L &L = t.lv[l];
     const int local = g - L.first_group;
+    if (t.by_rows) {
+        const int tiles_x = (L.width + FE_TW - 1) / FE_TW;
+        const int rg = (int)__umulhi((uint32_t)local, L.inv_tiles_x);  // local / tiles_x
+        const int tx = local - rg * tiles_x, row = rg * 8 + xcd;
+        if (row >= batch * L.tiles_y) return;
+        const int frame = (int)__umulhi((uint32_t)row, L.inv_tiles_y);
+        fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0},
+                   PlaneBatch{nullptr, 0, 0}, PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count,
+                   batch, L.inv_tiles_x, margin, frame * tiles_x + tx, row - frame * L.tiles_y);
+        return;
+    }
     const int cg = (int)__umulhi((uint32_t)local, L.inv_tiles_y);  // local / tiles_y
     const int ty = local - cg * L.tiles_y;
     fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
@@ -777,6 +802,13 @@ extern "C" int vo_debug_fe_stamps(unsigned long long *out)
 }
 #endif
 
+// VO_TILE_ORDER=cols restores the column-major tile order (for A/B measurements)
+static bool tile_order_by_rows()
+{
+    static const bool v = [] { const char *e = getenv("VO_TILE_ORDER"); return !(e && e[0] == 'c'); }();
+    return v;
+}
+
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
                      int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
                      uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s, int margin)
@@ -784,20 +816,26 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     // block b serves XCD group b % 8, which owns the tile columns congruent to
     // b % 8; the grid holds the largest group's tile count for every group
     const int tiles_x = (width + FE_TW - 1) / FE_TW, ncols = tiles_x * batch, tiles_y = (height + FE_TH - 1) / FE_TH;
+    const bool by_rows = tile_order_by_rows();
     dim3 grid(8 * tiles_y, (ncols + 7) / 8);
+    if (by_rows) grid = dim3(8 * tiles_x, (tiles_y * batch + 7) / 8);
     // floor(col / tiles_x) == umulhi(col, inv) for col * tiles_x < 2^32
     const uint32_t inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
+    const uint32_t inv_tiles_y = by_rows ? (uint32_t)(0x100000000ull / (uint32_t)tiles_y) + 1u : 0u;
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     margin = margin < 3 ? 3 : margin;  // cv::FAST itself never evaluates the outer 3 pixels
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
+                           inv_tiles_y);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
+                           inv_tiles_y);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
-                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin);
+                           src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
+                           inv_tiles_y);
 }
 
 void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t *pyr, uint8_t *pyr_blur,
@@ -806,6 +844,7 @@ void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t 
 {
     FeLevels t{};
     t.frame_stride = plan.frame_bytes;
+    t.by_rows = tile_order_by_rows() ? 1 : 0;
     int groups = 0;
     for (int l = first_level; l < plan.nlevels; l++) {
         const OrbLevel &P = plan.lv[l];
@@ -819,7 +858,7 @@ void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t 
         L.inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
         L.inv_tiles_y = (uint32_t)(0x100000000ull / (uint32_t)tiles_y) + 1u;
         L.first_group = groups;
-        groups += tiles_y * ((tiles_x * batch + 7) / 8);
+        groups += t.by_rows ? tiles_x * ((tiles_y * batch + 7) / 8) : tiles_y * ((tiles_x * batch + 7) / 8);
     }
     if (t.n == 0) return;
     t.total_groups = groups;
