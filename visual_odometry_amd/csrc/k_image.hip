@@ -201,18 +201,21 @@ __device__ __forceinline__ uint32_t quick_pair(uint32_t up1, uint32_t d0, uint32
 }
 
 // 7-tap row sums [18,34,49,55,49,34,18] of the four pixels at window bytes
-// 4..7, two 4-byte dot products each, packed as two u16 pairs
+// 4..7, two 4-byte dot products each.  Pixels 0 and 1 read the same two dwords
+// (window bytes 1..8) with the taps shifted by one byte, pixels 2 and 3 likewise
+// (bytes 3..10): four byte alignments for the quad.
 __device__ __forceinline__ void hsum7_quad(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t (&h)[4])
 {
-    constexpr uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps 0..3
-    constexpr uint32_t WB = 49u | (34u << 8) | (18u << 16);               // taps 4..6
-    h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), WA,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), WB, 0u, false), false);
-    h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), WA,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), WB, 0u, false), false);
-    h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), WA,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), WB, 0u, false), false);
-    h[3] = __builtin_amdgcn_udot4(d1, WA, __builtin_amdgcn_udot4(d2, WB, 0u, false), false);
+    constexpr uint32_t WA = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps 0..3 | window starts at tap 0
+    constexpr uint32_t WB = 49u | (34u << 8) | (18u << 16);               // taps 4..6, -
+    constexpr uint32_t XA = (18u << 8) | (34u << 16) | (49u << 24);       // -, taps 0..2 | window starts one byte early
+    constexpr uint32_t XB = 55u | (49u << 8) | (34u << 16) | (18u << 24);  // taps 3..6
+    const uint32_t a1 = __builtin_amdgcn_alignbyte(d1, d0, 1), b1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+    const uint32_t a3 = __builtin_amdgcn_alignbyte(d1, d0, 3), b3 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+    h[0] = __builtin_amdgcn_udot4(a1, WA, __builtin_amdgcn_udot4(b1, WB, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(a1, XA, __builtin_amdgcn_udot4(b1, XB, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(a3, WA, __builtin_amdgcn_udot4(b3, WB, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(a3, XA, __builtin_amdgcn_udot4(b3, XB, 0u, false), false);
 }
 
 constexpr int FE_TASKS = FE_GROWS * (FE_PITCH / 4);  // 4-pixel staging tasks per tile
@@ -236,26 +239,47 @@ struct FeTile {
 };
 
 // gray weights split into byte planes for 4-byte dot products:
-// gray = (dot4(px, lo) + (dot4(px, hi) << 8) + round) >> shift
+// gray = (dot4(px, lo) + (dot4(px, hi) << 8) + round) >> shift.
+// When the weights scaled by 2^(16 - shift) still fit 16 bits (the usual 14- and 15-bit tables do), the planes hold
+// the scaled weights instead: the sum is then gray << 16 plus a fraction and the result is its byte 2 -- no final
+// shift, and four results are packed with byte permutes (byte2 is set).
 struct GrayDot {
     uint32_t lo, hi, round;
     int shift;
+    bool byte2;
 };
 __device__ __forceinline__ GrayDot gray_dot(GrayCoeffs c)
 {
     GrayDot g;
-    g.lo = ((uint32_t)c.b & 255u) | (((uint32_t)c.g & 255u) << 8) | (((uint32_t)c.r & 255u) << 16);
-    g.hi = (((uint32_t)c.b >> 8) & 255u) | ((((uint32_t)c.g >> 8) & 255u) << 8) | ((((uint32_t)c.r >> 8) & 255u) << 16);
+    uint32_t cb = (uint32_t)c.b, cg = (uint32_t)c.g, cr = (uint32_t)c.r;
     g.round = 1u << (c.shift - 1);
     g.shift = c.shift;
+    g.byte2 = false;
+    if (c.shift <= 16) {
+        const int up = 16 - c.shift;
+        if (((cb << up) | (cg << up) | (cr << up)) < 65536u && c.b >= 0 && c.g >= 0 && c.r >= 0) {
+            cb <<= up; cg <<= up; cr <<= up;
+            g.round = 1u << 15;
+            g.shift = 16;
+            g.byte2 = true;
+        }
+    }
+    g.lo = (cb & 255u) | ((cg & 255u) << 8) | ((cr & 255u) << 16);
+    g.hi = ((cb >> 8) & 255u) | (((cg >> 8) & 255u) << 8) | (((cr >> 8) & 255u) << 16);
     return g;
 }
-// px holds B, G, R in its three low bytes (the fourth byte is ignored)
-__device__ __forceinline__ uint32_t gray_dot_px(uint32_t px, GrayDot g)
+// px holds B, G, R in its three low bytes (the fourth byte is ignored): the weighted sum before the final shift
+__device__ __forceinline__ uint32_t gray_dot_sum(uint32_t px, GrayDot g)
 {
     const uint32_t lo = __builtin_amdgcn_udot4(px, g.lo, g.round, false);
     const uint32_t hi = __builtin_amdgcn_udot4(px, g.hi, 0u, false);
-    return (lo + (hi << 8)) >> g.shift;
+    return lo + (hi << 8);
+}
+__device__ __forceinline__ uint32_t gray_dot_px(uint32_t px, GrayDot g) { return gray_dot_sum(px, g) >> g.shift; }
+// bytes 2 of four sums -> one dword
+__device__ __forceinline__ uint32_t pack_byte2(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3)
+{
+    return __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u) | __builtin_amdgcn_perm(s3, s2, 0x06020c0cu);
 }
 
 // BORDER_REFLECT_101 for positions at most len - 1 outside [0, len), clamped
@@ -328,6 +352,9 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
 {
     uint32_t out = 0;
     if (CN == 4) {
+        if (g.byte2)
+            return pack_byte2(gray_dot_sum(p.v[0], g), gray_dot_sum(p.v[1], g), gray_dot_sum(p.v[2], g),
+                              gray_dot_sum(p.v[3], g));
 #pragma unroll
         for (int j = 0; j < 4; j++) out |= gray_dot_px(p.v[j], g) << (8 * j);
     } else if (CN == 1) {
@@ -336,6 +363,9 @@ __device__ __forceinline__ uint32_t fe_gray4(const FePre<CN> &p, bool packed, Gr
     } else if (packed) {
         // 12 bytes B0 G0 R0 B1 ... R3 in three dwords: pixel j starts at byte 3j
         const uint32_t d0 = p.v[0], d1 = p.v[1], d2 = p.v[2];
+        if (g.byte2)
+            return pack_byte2(gray_dot_sum(d0, g), gray_dot_sum(__builtin_amdgcn_alignbyte(d1, d0, 3), g),
+                              gray_dot_sum(__builtin_amdgcn_alignbyte(d2, d1, 2), g), gray_dot_sum(d2 >> 8, g));
         out = gray_dot_px(d0, g) | (gray_dot_px(__builtin_amdgcn_alignbyte(d1, d0, 3), g) << 8) |
               (gray_dot_px(__builtin_amdgcn_alignbyte(d2, d1, 2), g) << 16) | (gray_dot_px(d2 >> 8, g) << 24);
     } else {
@@ -571,21 +601,25 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
             for (int i = 0; i <= 4 * FE_QPT; i++) total += (uint32_t)__popcll(m[i]);
             if (total) {
                 uint32_t base = 0;
+                const uint32_t q0 = (uint32_t)(((gy + 4) << 8) + 4 + 4 * gx);
                 if (lane == 0) base = atomicAdd(&s_qcount, total);
                 base = __builtin_amdgcn_readfirstlane(base);
+                // byte offsets into the queue: 2 * (base + passing lanes below this one); lanes that did not pass
+                // write their own spare slot past the queue (unconditional stores)
+                uint32_t base2 = 2u * base;
+                const uint32_t spare2 = 2u * (uint32_t)(FE_QCAP + lane);
+                uint8_t *qb = reinterpret_cast<uint8_t *>(s_queue);
 #pragma unroll
                 for (int i = 0; i < 4 * FE_QPT; i++) {
-                    // base + number of passing lanes below this one
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
-                        (uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], base));
-                    const uint32_t q = (uint32_t)(((gy + 16 * (i >> 2) + 4) << 8) | (4 + 4 * gx + (i & 3)));
-                    // unconditional store: lanes that did not pass write their own spare slot past the queue
-                    s_queue[pass[i] ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)q;
-                    base += (uint32_t)__popcll(m[i]);
+                    const uint32_t below =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(m[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[i], 0u));
+                    const uint32_t q = q0 + (uint32_t)((16 * (i >> 2)) << 8 | (i & 3));  // row gy + 16 k + 4, column 4 + 4 gx + i
+                    *reinterpret_cast<uint16_t *>(qb + (pass[i] ? (below << 1) + base2 : spare2)) = (uint16_t)q;
+                    base2 += 2u * (uint32_t)__popcll(m[i]);
                 }
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi(
-                    (uint32_t)(m[4 * FE_QPT] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[4 * FE_QPT], base));
-                s_queue[hr >= 0 ? pos : (uint32_t)(FE_QCAP + lane)] = (uint16_t)((hr << 8) | hc);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[4 * FE_QPT] >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m[4 * FE_QPT], 0u));
+                *reinterpret_cast<uint16_t *>(qb + (hr >= 0 ? (below << 1) + base2 : spare2)) = (uint16_t)((hr << 8) | hc);
             }
         }
         FE_STAMP(4);
@@ -687,23 +721,25 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
         // even row: taps (18,34)(49,55)(49,34)(18,-); odd row: (-,18)(34,49)(55,49)(34,18)
         constexpr uint32_t E0 = 18u | (34u << 16), E1 = 49u | (55u << 16), E2 = 49u | (34u << 16), E3 = 18u;
         constexpr uint32_t O0 = 18u << 16, O1 = 34u | (49u << 16), O2 = 55u | (49u << 16), O3 = 34u | (18u << 16);
-        uint32_t oe = 0, oo = 0;
         const uint32_t col[4][4] = {{P[0].x, P[1].x, P[2].x, P[3].x}, {P[0].y, P[1].y, P[2].y, P[3].y},
                                     {P[0].z, P[1].z, P[2].z, P[3].z}, {P[0].w, P[1].w, P[2].w, P[3].w}};
+        // The accumulators start at 0xff000000 + the rounding constant and the dot products saturate at 2^32 - 1:
+        // byte 2 of the result is then min((sum + 2^15) >> 16, 255) without a shift or a compare.
+        uint32_t ae[4], ao[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t ae = 1u << 15, ao = 1u << 15;
-            ae = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(E0), ae, false);
-            ae = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(E1), ae, false);
-            ae = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(E2), ae, false);
-            ae = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(E3), ae, false);
-            ao = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(O0), ao, false);
-            ao = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(O1), ao, false);
-            ao = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(O2), ao, false);
-            ao = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(O3), ao, false);
-            oe |= min(ae >> 16, 255u) << (8 * i);
-            oo |= min(ao >> 16, 255u) << (8 * i);
+            ae[i] = ao[i] = 0xff008000u;
+            ae[i] = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(E0), ae[i], true);
+            ae[i] = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(E1), ae[i], true);
+            ae[i] = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(E2), ae[i], true);
+            ae[i] = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(E3), ae[i], true);
+            ao[i] = __builtin_amdgcn_udot2(as_us2(col[i][0]), as_us2(O0), ao[i], true);
+            ao[i] = __builtin_amdgcn_udot2(as_us2(col[i][1]), as_us2(O1), ao[i], true);
+            ao[i] = __builtin_amdgcn_udot2(as_us2(col[i][2]), as_us2(O2), ao[i], true);
+            ao[i] = __builtin_amdgcn_udot2(as_us2(col[i][3]), as_us2(O3), ao[i], true);
         }
+        // bytes 2 of four sums -> one dword
+        const uint32_t oe = pack_byte2(ae[0], ae[1], ae[2], ae[3]), oo = pack_byte2(ao[0], ao[1], ao[2], ao[3]);
         const int yy = y0 + 2 * m, xx = x0 + tg * 4;
         uint8_t *bp = blur.base + f * blur.plane_stride + (size_t)yy * blur.pitch + xx;
         if (yy < height) *reinterpret_cast<uint32_t *>(bp) = oe;
