@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """HBM bytes per launch of the image stages from a FETCH_SIZE / WRITE_SIZE summary (pmcstats.py output of the two
 --pmc passes of `python3 bench.py --cpu-frames 0 --steps 3 --warmup 1`): writes the JSON bench.py reads for
-`roofline.traffic`.  FETCH_SIZE is doubled for the kernels whose loads are 16 bytes per lane (the level-0 tile
-kernel on BGRA input, the resize kernel), as the counter tallies 128-byte requests at 64 bytes on gfx950.  The
-gray-input instantiation of the tile kernel is taken as read: run on a gray copy of the BGRA frames (same tiles,
-a quarter of the bytes) it reads 0.483 of the BGRA run's raw value, not 0.25, and 1.37 x the plane's bytes, which
-is the apron re-read its 128x32 tiles imply (tools/calib_fetch.py, profiles/calib.sh).  Other kernels with narrow
-loads are left uncalibrated (bytes = null)."""
+`roofline.traffic`, stamped with the SHA-256 of the kernel sources the counters were taken on (bench.py refuses
+the file when the tree's sources hash differently).
+
+FETCH_SIZE is doubled for every kernel: a kernel that reads a 512 MiB buffer exactly once reports 262 200 KB with
+aligned 16-byte loads, 262 200 KB with 4-byte loads and 270 300 KB with 16-byte loads at 4-byte alignment
+(tools/fetch_probe.hip, profiles/r02_fetch_probe.txt) -- the counter tallies the 128-byte requests of gfx950 at
+64 bytes whatever the load shape.  WRITE_SIZE reads true in the same probe.
+
+  python3 profiles/traffic.py <pmc_hbm.txt> <frames per launch> <out.json> [<pmc_sq.txt> <kernel_stats.csv>]
+"""
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
+    from bench import kernel_source_hash
     kb = {}
     for line in open(path):
         parts = line.split()
@@ -28,26 +36,18 @@ def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
         return None
 
     stages = {}
-    d = find("k_frontendILi4E")
-    if d:
-        stages["frontend_fast_nms_blur"] = {
-            "bytes": (2 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024,
-            "note": "2 x FETCH_SIZE (16-byte loads) + WRITE_SIZE, one launch"}
-    d = find("k_resize_exact")
-    if d:
-        n = d["FETCH_SIZE"][1] // max(1, find("k_frontendILi4E")["FETCH_SIZE"][1])  # launches per batch
-        stages["pyramid_resize"] = {
-            "bytes": (2 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024 * n,
-            "note": f"{n} launches; 2 x FETCH_SIZE (16-byte loads) + WRITE_SIZE"}
-    d = find("k_frontendILi1E")
-    if d:
-        n = d["FETCH_SIZE"][1] // max(1, find("k_frontendILi4E")["FETCH_SIZE"][1])
-        stages["frontend_upper_levels"] = {
-            "bytes": (d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024 * n,
-            "fetch_bytes": d["FETCH_SIZE"][0] * 1024 * n, "write_bytes": d["WRITE_SIZE"][0] * 1024 * n,
-            "note": f"{n} launches; FETCH_SIZE as read + WRITE_SIZE: on 1-byte gray input the counter reads the staged "
-                    "bytes themselves (calibrated against the BGRA instantiation on the same tiles, "
-                    "r01_fetch_calibration.txt)"}
+    lvl0 = find("k_frontendILi4E")
+    steps = lvl0["FETCH_SIZE"][1] if lvl0 else 1          # one level-0 launch per batch
+    for stage, frag in (("frontend_fast_nms_blur", "k_frontendILi4E"), ("pyramid_resize", "k_resize_exact"),
+                        ("frontend_upper_levels", "k_frontend_levels"), ("brief", "k_brief_steered"),
+                        ("knn2", "k_knn2"), ("select_topn_rank", "k_orb_select"), ("select_topn_finish", "k_orb_finish")):
+        d = find(frag)
+        if not d or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
+        n = max(1, d["FETCH_SIZE"][1] // max(1, steps))   # launches per batch (the averages are per launch)
+        fetch, write = 2 * d["FETCH_SIZE"][0] * 1024 * n, d["WRITE_SIZE"][0] * 1024 * n
+        stages[stage] = {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+                         "note": f"{n} launch(es) per batch; 2 x FETCH_SIZE + WRITE_SIZE"}
     # vector-ALU occupancy of the same kernels: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, so
     # busy = 4 * count / (1024 SIMDs * 2.4 GHz * average kernel duration from the kernel trace)
     if sq_path and kstats_path:
@@ -61,14 +61,17 @@ def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
             if line.startswith('"'):
                 name, rest = line[1:].split('",', 1)
                 dur[name] = float(rest.split(",")[2]) * 1e-6  # avg_us
-        for stage, frag in (("frontend_fast_nms_blur", "k_frontendILi4E"), ("frontend_upper_levels", "k_frontendILi1E"),
-                            ("knn2", "k_knn2"), ("pyramid_resize", "k_resize_exact"), ("brief", "k_brief")):
+        for stage, frag in (("frontend_fast_nms_blur", "k_frontendILi4E"), ("frontend_upper_levels", "k_frontend_levels"),
+                            ("knn2", "k_knn2"), ("pyramid_resize", "k_resize_exact"), ("brief", "k_brief_steered")):
             a = next((v for k, v in sq.items() if frag in k), None)
             d = next((v for k, v in dur.items() if frag in k), None)
             if a and d:
-                stages.setdefault(stage, {"bytes": None})["valu_busy"] = round(
-                    4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * 2.4e9 * d), 3)
-    json.dump({"frames_per_launch": frames_per_launch, "source": path, "stages": stages}, open(out, "w"), indent=1)
+                st = stages.setdefault(stage, {"bytes": None})
+                st["valu_busy"] = round(4 * a["SQ_ACTIVE_INST_VALU"] / (1024 * 2.4e9 * d), 3)
+                if a.get("SQ_WAVES"):
+                    st["valu_insts_per_wave"] = round(a["SQ_INSTS_VALU"] / a["SQ_WAVES"], 1)
+    json.dump({"frames_per_launch": frames_per_launch, "source": os.path.basename(path),
+               "source_hash": kernel_source_hash(), "stages": stages}, open(out, "w"), indent=1)
     print(json.dumps(stages, indent=1))
 
 

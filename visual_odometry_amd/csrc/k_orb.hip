@@ -20,6 +20,25 @@ namespace {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
+// Frame-per-XCD block order for kernels whose blocks of one frame read overlapping lines.  The grid is 1-D with
+// per_frame * batch blocks and consecutive blocks go to consecutive XCDs.  When the batch is a multiple of eight,
+// XCD x = block % 8 works through frames x, x + 8, ... one after the other, a frame's blocks in order, so that the
+// frame's lines are fetched into one L2 only; other batches (a single frame above all) keep the plain order, which
+// spreads every frame over all XCDs.
+struct FrameBlock {
+    int frame, block;
+};
+__device__ __forceinline__ FrameBlock frame_block(int per_frame, int batch)
+{
+    if (batch & 7) {
+        const int frame = (int)blockIdx.x / per_frame;
+        return FrameBlock{frame, (int)blockIdx.x - frame * per_frame};
+    }
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int group = slot / per_frame;
+    return FrameBlock{group * 8 + xcd, slot - group * per_frame};
+}
+
 // ------------------------------------------------------------------ resize
 
 constexpr int RZ_TW = 128, RZ_TH = 32, RZ_THREADS = 256;
@@ -41,12 +60,15 @@ static_assert(RZ_TH == kResizeRowPad, "row tables are padded to whole resize til
 // column's tap pair and one v_dot2_u32_u16 weighs it.
 __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
                                                             int dh, const uint32_t *__restrict__ xtab,
-                                                            const uint32_t *__restrict__ ytab)
+                                                            const uint32_t *__restrict__ ytab, int tiles_x,
+                                                            int tiles_y, int batch)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP + 16];
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * RZ_TW, y0 = blockIdx.y * RZ_TH, f = blockIdx.z;
+    const FrameBlock fb = frame_block(tiles_x * tiles_y, batch);  // a frame's tiles in raster order on one XCD
+    const int ty = fb.block / tiles_x, tx = fb.block - ty * tiles_x;
+    const int x0 = tx * RZ_TW, y0 = ty * RZ_TH, f = fb.frame;
     // block-uniform footprint (tables are padded to whole tiles with their last entry)
     const int sx_lo = (int)(xtab[x0] & 0xffffu) & ~15;
     const int sx_hi = min((int)(xtab[x0 + RZ_TW - 1] & 0xffffu) + 1, sw - 1);
@@ -423,11 +445,13 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
                                                           const uint32_t *__restrict__ lvl_ras,
                                                           const float *__restrict__ lvl_resp,
                                                           const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
-                                                          int kp_stride, int kp_cap, int *__restrict__ nkp)
+                                                          int kp_stride, int kp_cap, int *__restrict__ nkp,
+                                                          int blocks_per_frame, int batch)
 {
     __shared__ uint32_t s_mask[16][OF_LANES];
-    const int f = blockIdx.y, gl = threadIdx.x & (OF_LANES - 1);
-    const int i = blockIdx.x * OF_KPB + (threadIdx.x >> 3);
+    const FrameBlock fb = frame_block(blocks_per_frame, batch);
+    const int f = fb.frame, gl = threadIdx.x & (OF_LANES - 1);
+    const int i = fb.block * OF_KPB + (threadIdx.x >> 3);
     if (threadIdx.x < 16 * OF_LANES) {
         // byte j of s_mask[v][q]: column u = -15 + 4q + j lies inside the disc at row |v|
         const int v = threadIdx.x >> 3, q = threadIdx.x & 7;
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
         total += n;
     }
     total = min(total, kp_cap);  // vo_cfg.max_features: what the caller's arrays hold (kp_stride is padded)
-    if (blockIdx.x == 0 && threadIdx.x == 0) nkp[f] = total;
+    if (fb.block == 0 && threadIdx.x == 0) nkp[f] = total;
     const bool live = level >= 0 && i < total;
     const int lv = live ? level : 0;
     const int Lpitch = plan.lv[lv].pitch;
@@ -522,20 +546,21 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
                                                       const vo_kp *__restrict__ kps, int kp_stride,
                                                       const int *__restrict__ nkp,
                                                       const int8_t *__restrict__ pattern,
-                                                      uint8_t *__restrict__ desc)
+                                                      uint8_t *__restrict__ desc, int blocks_per_frame, int batch)
 {
     __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
     __shared__ float s_cs[8][2];
+    const FrameBlock fb = frame_block(blocks_per_frame, batch);
     reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
-    const int f = blockIdx.y;
-    const int g = threadIdx.x >> 5, k = blockIdx.x * 8 + g;
+    const int f = fb.frame;
+    const int g = threadIdx.x >> 5, k = fb.block * 8 + g;
     const int byte = threadIdx.x & 31;
     const int n_kp = nkp[f];
     const bool live = k < n_kp;
     // double-precision cos / sin of the block's eight angles: one lane each, in a single wave
-    if (threadIdx.x < 8 && blockIdx.x * 8 + (int)threadIdx.x < n_kp) {
-        float angle = kps[(size_t)f * kp_stride + blockIdx.x * 8 + threadIdx.x].angle;
+    if (threadIdx.x < 8 && fb.block * 8 + (int)threadIdx.x < n_kp) {
+        float angle = kps[(size_t)f * kp_stride + fb.block * 8 + threadIdx.x].angle;
         angle *= (float)(3.14159265358979323846 / 180.f);
         s_cs[threadIdx.x][0] = (float)cos((double)angle);
         s_cs[threadIdx.x][1] = (float)sin((double)angle);
@@ -688,8 +713,9 @@ extern "C" int vo_debug_os_stamps(unsigned long long *out)
 void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw, int dh, const uint32_t *xtab,
                          const uint32_t *ytab, int batch, hipStream_t s)
 {
-    dim3 grid((dw + RZ_TW - 1) / RZ_TW, (dh + RZ_TH - 1) / RZ_TH, batch);
-    hipLaunchKernelGGL(k_resize_exact, grid, dim3(RZ_THREADS), 0, s, src, sw, sh, dst, dw, dh, xtab, ytab);
+    const int tiles_x = (dw + RZ_TW - 1) / RZ_TW, tiles_y = (dh + RZ_TH - 1) / RZ_TH;
+    hipLaunchKernelGGL(k_resize_exact, dim3((unsigned)(tiles_x * tiles_y * batch)), dim3(RZ_THREADS), 0, s, src, sw,
+                       sh, dst, dw, dh, xtab, ytab, tiles_x, tiles_y, batch);
 }
 
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
@@ -704,16 +730,17 @@ void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const
                        const float *lvl_resp, const int *lvl_n, vo_kp *kps, int kp_stride, int kp_cap, int *nkp,
                        hipStream_t s)
 {
-    dim3 grid((kp_stride + OF_KPB - 1) / OF_KPB, batch);
-    hipLaunchKernelGGL(k_orb_finish, grid, dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras, lvl_resp, lvl_n, kps,
-                       kp_stride, kp_cap, nkp);
+    const int per_frame = (kp_stride + OF_KPB - 1) / OF_KPB;
+    hipLaunchKernelGGL(k_orb_finish, dim3((unsigned)(per_frame * batch)), dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras,
+                       lvl_resp, lvl_n, kps, kp_stride, kp_cap, nkp, per_frame, batch);
 }
 
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
                           const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s)
 {
-    dim3 grid((kp_stride + 7) / 8, batch);
-    hipLaunchKernelGGL(k_brief_steered, grid, dim3(256), 0, s, plan, pyr_blur, kps, kp_stride, nkp, pattern, desc);
+    const int per_frame = (kp_stride + 7) / 8;
+    hipLaunchKernelGGL(k_brief_steered, dim3((unsigned)(per_frame * batch)), dim3(256), 0, s, plan, pyr_blur, kps,
+                       kp_stride, nkp, pattern, desc, per_frame, batch);
 }
 
 }  // namespace vo
