@@ -478,7 +478,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
                                         size_t src_frame_stride, PlaneBatch gray_out, PlaneBatch score,
                                         PlaneBatch blur, int thr, GrayCoeffs c, uint32_t *__restrict__ cand,
                                         uint32_t *__restrict__ tile_count, int batch, uint32_t inv_tiles_x,
-                                        int margin, int col, int ty)
+                                        int margin, int col, int ty, int unused_edge = 0)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
@@ -506,6 +506,14 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
                      tile.y0 + FE_TH <= height - margin;
     }
     const int x0 = tile.x0, y0 = tile.y0, f = tile.frame;
+
+    // A tile that starts within `unused_edge` pixels of the right or bottom edge holds nothing a later stage reads
+    // (no corners are looked for there: unused_edge <= margin; the caller reads the blurred plane only further
+    // inside): it only reports an empty corner list.
+    if (unused_edge > 0 && unused_edge <= margin && (x0 >= width - unused_edge || y0 >= height - unused_edge)) {
+        if (cand && tid == 0) tile_count[(size_t)f * tiles_x * tiles_y + (y0 / FE_TH) * tiles_x + x0 / FE_TW] = 0;
+        return;
+    }
 
     FE_STAMP(0);
     // ---- 0. stage
@@ -801,6 +809,7 @@ struct FeLevels {
     } lv[kOrbMaxLevels];
     int total_groups;
     int by_rows;          // groups enumerate (tile-row group, tile column) instead of (tile-column group, tile row)
+    int unused_edge;      // tiles that start this close to the right / bottom edge are skipped (see fe_tile)
     size_t frame_stride;  // bytes between the planes of consecutive frames (same for input and output)
 };
 
@@ -821,14 +830,14 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_levels(FeLevels t, int 
         const int frame = (int)__umulhi((uint32_t)row, L.inv_tiles_y);
         fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0},
                    PlaneBatch{nullptr, 0, 0}, PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count,
-                   batch, L.inv_tiles_x, margin, frame * tiles_x + tx, row - frame * L.tiles_y);
+                   batch, L.inv_tiles_x, margin, frame * tiles_x + tx, row - frame * L.tiles_y, t.unused_edge);
         return;
     }
     const int cg = (int)__umulhi((uint32_t)local, L.inv_tiles_y);  // local / tiles_y
     const int ty = local - cg * L.tiles_y;
     fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
                PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count, batch, L.inv_tiles_x, margin,
-               cg * 8 + xcd, ty);
+               cg * 8 + xcd, ty, t.unused_edge);
 }
 
 #ifdef VO_FE_STAMPS
@@ -881,6 +890,10 @@ void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t 
     FeLevels t{};
     t.frame_stride = plan.frame_bytes;
     t.by_rows = tile_order_by_rows() ? 1 : 0;
+    // the steered descriptor samples at most kBriefReach pixels from a key point, and key points lie kFBorder
+    // pixels inside the level: the outermost kFBorder - kBriefReach columns and rows of the blurred level are
+    // never read
+    t.unused_edge = kFBorder - kBriefReach;
     int groups = 0;
     for (int l = first_level; l < plan.nlevels; l++) {
         const OrbLevel &P = plan.lv[l];

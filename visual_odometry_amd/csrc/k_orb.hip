@@ -534,7 +534,7 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
 // 31x31 pattern rotated by the keypoint angle per sample (float32, cvRound).
 // The pattern's largest radius is 18.4 px, so every rotated sample lies within
 // +-18 px: the 37 x 37 patch is staged in LDS with dword loads first.
-constexpr int BS_R = 18;
+constexpr int BS_R = kBriefReach;
 // low 24 bits of the float 1.5 * 2^23 + n are 0x400000 + n
 constexpr int kBriefRoundBias = 0x400000;
 __device__ __forceinline__ int brief_round_bits(float v)
