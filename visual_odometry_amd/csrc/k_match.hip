@@ -22,6 +22,13 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// the same for signed values (v_med3_i32)
+__device__ __forceinline__ int imed3(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // Key scale: a key is kKeyScale * distance + train index, so the scale must exceed every train index
 // (vo_cfg.max_features <= 6144) -- and it is twice the magnitude of the byte product of the MFMA operands,
@@ -66,6 +73,7 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
             uint2 *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[3][KNN_TILE * KNN_ROW];  // tiles t, t+1, t+2
+    __shared__ uint32_t s_lut[16];  // four descriptor bits -> four bytes +64 (bit set) / -64
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -78,10 +86,15 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     const int col = lane & 31, half = lane >> 5;  // MFMA column (query) / row (train) and K half of this lane
     const uint4 *qd = reinterpret_cast<const uint4 *>(desc + qs * slot_stride);
     const uint32_t *td = reinterpret_cast<const uint32_t *>(desc + ts * slot_stride);
+    if (tid < 16) s_lut[tid] = nibble_spread<7>((uint32_t)tid, 0) ^ 0xc0c0c0c0u;
 
     // B operands: bits 32 ks + 16 half .. + 15 of the lane's two queries as bytes -48 (bit set) / +48
     v4i B[2][8];
-    uint32_t k0[2], k1[2];
+    // Running two smallest keys of the lane's two queries, RELATIVE to the first train of the tile they were last
+    // updated with (signed: an earlier train at distance 0 has a negative relative key).  Keeping the tile's
+    // accumulator start values fixed and moving these four registers by one tile per step costs 4 vector
+    // instructions per step instead of 16.
+    int k0[2], k1[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const int q = min(qbase + wave * KNN_QPW + 32 * s + col, nq - 1);
@@ -96,7 +109,7 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
                 B[s][ks][j] = (int)(0x30303030u ^ ((m << 3) - m));     // 0x30 ^ 0xe0 = 0xd0 = -48
             }
         }
-        k0[s] = k1[s] = 0xffffffffu;
+        k0[s] = k1[s] = 0x7fffffff;
     }
 
     // this block's share of the train set: an even cut of the descriptors
@@ -106,19 +119,31 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
 
     // staging role of this thread: word sc of train sr of the tile
     const int sr = tid >> 3, sc = tid & 7;
-    auto load_packed = [&](int t) -> uint32_t {
-        return td[(size_t)min(j_lo + t * KNN_TILE + sr, nt - 1) * 8 + sc];  // rows past the share: any train
+    int next_row = j_lo + sr;  // train row of the next packed word this thread loads
+    auto load_packed = [&]() -> uint32_t {
+        const uint32_t x = td[(size_t)min(next_row, nt - 1) * 8 + sc];  // rows past the share: any train
+        next_row += KNN_TILE;
+        return x;
     };
-    auto stage = [&](int buf, uint32_t x) {
-        uint32_t e[8];  // bytes +64 (bit set) / -64
+    // the two 16-byte halves of words 4 .. 7 are swapped, so that the eight lanes of a train write (and the
+    // MFMA operand reads below fetch) distinct banks
+    const int stage_at = sr * KNN_ROW + 32 * sc, stage_sw = (sc >> 2) * 16;
+    auto stage_store = [&](int buf, const uint32_t (&e)[8]) {
+        uint8_t *row = &s_a[buf][stage_at];
+        *reinterpret_cast<uint4 *>(row + stage_sw) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4 *>(row + (16 - stage_sw)) = make_uint4(e[4], e[5], e[6], e[7]);
+    };
+    // expansion of a packed word to bytes +64 (bit set) / -64: arithmetic (prologue) or through the table in LDS
+    // (steady state: two vector instructions and one LDS read per four bits instead of five instructions)
+    auto expand = [&](uint32_t x, uint32_t (&e)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) e[i] = nibble_spread<7>(x, i) ^ 0xc0c0c0c0u;
-        // the two 16-byte halves of words 4 .. 7 are swapped, so that the eight lanes of a train write (and the
-        // MFMA operand reads below fetch) distinct banks
-        uint8_t *row = &s_a[buf][sr * KNN_ROW + 32 * sc];
-        const int sw = (sc >> 2) * 16;
-        *reinterpret_cast<uint4 *>(row + sw) = make_uint4(e[0], e[1], e[2], e[3]);
-        *reinterpret_cast<uint4 *>(row + (16 - sw)) = make_uint4(e[4], e[5], e[6], e[7]);
+    };
+    auto expand_lut = [&](uint32_t x, uint32_t (&e)[8]) {
+        const uint8_t *lut = reinterpret_cast<const uint8_t *>(s_lut);
+        e[0] = *reinterpret_cast<const uint32_t *>(lut + ((x << 2) & 0x3cu));
+#pragma unroll
+        for (int i = 1; i < 8; i++) e[i] = *reinterpret_cast<const uint32_t *>(lut + ((x >> (4 * i - 2)) & 0x3cu));
     };
 
     // One step = one tile.  The two accumulation chains of a tile (query sets 0 and 1) are issued one after
@@ -127,8 +152,8 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     // of tile t and set 0 of tile t under chain 1 of tile t.
     auto update = [&](int s, int key) {
         // k0 <= k1: the two smallest of {k0, k1, key} are min(k0, key) and the median of the three
-        k1[s] = umed3(k0[s], k1[s], (uint32_t)key);
-        k0[s] = min(k0[s], (uint32_t)key);
+        k1[s] = imed3(k0[s], k1[s], key);
+        k0[s] = min(k0[s], key);
     };
     // the chain of query set s over the tile in A, with the updates of set 1 - s (accumulator `done`)
     // (gap(ks): further work for the issue gap after MFMA ks)
@@ -142,24 +167,29 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    const int op_lo = col * KNN_ROW + 16 * half, op_hi = col * KNN_ROW + 16 * (half ^ 1);
     auto operand = [&](int buf, int ks) {
-        return *reinterpret_cast<const v4i *>(&s_a[buf][col * KNN_ROW + 32 * ks + 16 * (half ^ (ks >> 2))]);
+        return *reinterpret_cast<const v4i *>(&s_a[buf][(ks < 4 ? op_lo : op_hi) + 32 * ks]);
     };
 
     v16i acc0, acc1, start;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        acc0[r] = acc1[r] = -1;  // "tile -1": keys that change nothing
-        // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile
-        start[r] = kKeyBias + j_lo + (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc0[r] = acc1[r] = 0x7fffffff;  // "tile -1": keys that change nothing
+        // accumulator register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 half of the tile: the key of that
+        // train relative to the tile's first one
+        start[r] = kKeyBias + (r & 3) + 8 * (r >> 2) + 4 * half;
     }
     // Three tiles live in LDS.  Step t expands tile t+2 (from packed words loaded during step t-1), runs the two
     // chains of tile t from registers and, as chain 1 releases them one by one, refills the operand registers
     // with tile t+1 (expanded during step t-1): the operand reads of a step are in flight during the MFMAs of
     // the step before, nothing is read right after the block barrier.
-    if (ntiles > 0) stage(0, load_packed(0));
-    if (ntiles > 1) stage(1, load_packed(1));
-    uint32_t next = ntiles > 2 ? load_packed(2) : 0u;
+    {
+        uint32_t e[8];
+        if (ntiles > 0) { expand(load_packed(), e); stage_store(0, e); }
+        if (ntiles > 1) { expand(load_packed(), e); stage_store(1, e); }
+    }
+    uint32_t next = ntiles > 2 ? load_packed() : 0u;
     __syncthreads();
     v4i A[8];
 #pragma unroll
@@ -167,42 +197,51 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     int bcur = 0;  // t % 3
     for (int t = 0; t < ntiles; t++) {
         const int bnext = bcur == 2 ? 0 : bcur + 1, bnext2 = bnext == 2 ? 0 : bnext + 1;
-        const bool more = t + 1 < ntiles;             // block-uniform
-        if (t + 2 < ntiles) stage(bnext2, next);
-        if (t + 3 < ntiles) next = load_packed(t + 3);
+        const bool fill = t + 2 < ntiles;             // block-uniform
+        uint32_t e[8];
+        if (fill) expand_lut(next, e);                // table reads in flight under chain 0
+        if (t + 3 < ntiles) next = load_packed();
         if (t == ntiles - 1) {
             // rows past the share (their bytes are some other train's): keys above every real one
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                if (start[r] - kKeyBias >= j_hi) start[r] = (int)kKeyNone + kKeyBias;
+                if (j_lo + t * KNN_TILE + start[r] - kKeyBias >= j_hi) start[r] = (int)kKeyNone + kKeyBias;
         }
+        // the running keys move on by one tile: set 0 becomes relative to tile t, whose keys it takes under chain 1;
+        // set 1 becomes relative to tile t-1, whose keys it takes under chain 0
+#pragma unroll
+        for (int s = 0; s < 2; s++) { k0[s] -= KNN_TILE; k1[s] -= KNN_TILE; }
         __builtin_amdgcn_sched_barrier(0);
         chain(0, acc0, start, A, acc1, [](int) {});
-        chain(1, acc1, start, A, acc0, [&](int ks) {
-            if (more) A[ks] = operand(bnext, ks);
-        });
-#pragma unroll
-        for (int r = 0; r < 16; r++) start[r] += KNN_TILE;
+        if (fill) stage_store(bnext2, e);
+        __builtin_amdgcn_sched_barrier(0);
+        // (after the last tile the refill reads a stale buffer: harmless, and no branch per operand)
+        chain(1, acc1, start, A, acc0, [&](int ks) { A[ks] = operand(bnext, ks); });
         // block barrier for the LDS tiles only: __syncthreads() would also wait for the packed words of tile
         // t+3, a global load that is meant to stay in flight across the barrier
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         bcur = bnext;
     }
-    // set 1 of the last tile
+    // Set 0 took tile t's keys in step t and is relative to the last tile now.  Set 1 takes tile t-1's keys in
+    // step t, so it is relative to the last tile but one: one more move, then the last tile's keys.
     if (ntiles > 0) {
+        k0[1] -= KNN_TILE;
+        k1[1] -= KNN_TILE;
 #pragma unroll
         for (int r = 0; r < 16; r++) update(1, acc1[r]);
     }
+    const int key_base = j_lo + (ntiles - 1) * KNN_TILE;
 
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         // the other half of the wave holds the other 16 rows of every tile for the same query
-        const uint32_t o0 = __shfl_xor(k0[s], 32), o1 = __shfl_xor(k1[s], 32);
-        const uint32_t n0 = min(k0[s], o0);
-        const uint32_t n1 = min(max(k0[s], o0), min(k1[s], o1));
+        const int o0 = __shfl_xor(k0[s], 32), o1 = __shfl_xor(k1[s], 32);
+        const int n0 = min(k0[s], o0);
+        const int n1 = min(max(k0[s], o0), min(k1[s], o1));
         // key -> (distance << 16) | train index
-        auto finish = [&](uint32_t k) {
-            if (k >= kKeyNone) return 0xffffffffu;
+        auto finish = [&](int rel) {
+            if (rel >= (int)kKeyNone) return 0xffffffffu;
+            const uint32_t k = (uint32_t)(rel + key_base);
             const uint32_t d = k / (uint32_t)kKeyScale, idx = k - d * (uint32_t)kKeyScale;
             return (d << 16) | idx;
         };
