@@ -545,14 +545,14 @@ constexpr int BS_PWD = (2 * BS_R + 1 + 3 + 3) / 4;
 __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8_t *__restrict__ pyr_blur,
                                                       const vo_kp *__restrict__ kps, int kp_stride,
                                                       const int *__restrict__ nkp,
-                                                      const int8_t *__restrict__ pattern,
+                                                      const float *__restrict__ pattern,
                                                       uint8_t *__restrict__ desc, int blocks_per_frame, int batch)
 {
-    __shared__ __attribute__((aligned(16))) int8_t s_pat[1024];
+    __shared__ float4 s_pat[256];  // [test of a byte][byte]: x0 y0 x1 y1
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
     __shared__ float s_cs[8][2];
     const FrameBlock fb = frame_block(blocks_per_frame, batch);
-    reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
+    s_pat[threadIdx.x] = reinterpret_cast<const float4 *>(pattern)[threadIdx.x];
     const int f = fb.frame;
     const int g = threadIdx.x >> 5, k = fb.block * 8 + g;
     const int byte = threadIdx.x & 31;
@@ -599,12 +599,11 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
     const float a = s_cs[g][0], b = s_cs[g][1];
     const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0 -
                             kBriefRoundBias * (BS_PWD * 4 + 1);
-    const int8_t *p = s_pat + byte * 32;
     uint32_t val = 0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const float x0 = (float)p[4 * t + 0], y0 = (float)p[4 * t + 1];
-        const float x1 = (float)p[4 * t + 2], y1 = (float)p[4 * t + 3];
+        const float4 p = s_pat[t * 32 + byte];
+        const float x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
         // cvRound by adding 1.5 * 2^23: the sum's low mantissa bits hold the coordinate rounded to nearest even
         // (|coordinate| < 2^22); the bias of the bit patterns is taken off the base address once
         const int ix0 = brief_round_bits(x0 * a - y0 * b), iy0 = brief_round_bits(x0 * b + y0 * a);
@@ -736,7 +735,7 @@ void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 }
 
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
-                          const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s)
+                          const int *nkp, const float *pattern, uint8_t *desc, hipStream_t s)
 {
     const int per_frame = (kp_stride + 7) / 8;
     hipLaunchKernelGGL(k_brief_steered, dim3((unsigned)(per_frame * batch)), dim3(256), 0, s, plan, pyr_blur, kps,

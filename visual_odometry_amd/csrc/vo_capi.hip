@@ -181,8 +181,17 @@ int vo_ctx::allocate()
     int8_t pat[1024];
     build_pattern(-1.0f, pat);
     HIP_TRY(ctx, hipMemcpy(d_pattern, pat, 1024, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc(&d_pattern0, 1024));
-    HIP_TRY(ctx, hipMemcpy(d_pattern0, vo_orb_bit_pattern_31, 1024, hipMemcpyHostToDevice));
+    {
+        // descriptor byte b, bit t is test 8 b + t: its four coordinates as floats at [(t * 32 + b) * 4], so that the
+        // 32 lanes of a key point (one per byte) read consecutive 16-byte entries
+        std::vector<float> patf(1024);
+        for (int b = 0; b < 32; b++)
+            for (int t = 0; t < 8; t++)
+                for (int c = 0; c < 4; c++)
+                    patf[(size_t)(t * 32 + b) * 4 + c] = (float)vo_orb_bit_pattern_31[(b * 8 + t) * 4 + c];
+        HIP_TRY(ctx, hipMalloc(&d_pattern0, 4096));
+        HIP_TRY(ctx, hipMemcpy(d_pattern0, patf.data(), 4096, hipMemcpyHostToDevice));
+    }
     pinned_bytes = std::max(kPinnedBytes, sizeof(vo_frame_result) * (size_t)B);
     HIP_TRY(ctx, hipHostMalloc(&h_pinned, pinned_bytes));
     return VO_OK;

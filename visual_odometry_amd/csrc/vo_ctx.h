@@ -51,7 +51,7 @@ struct vo_ctx {
     uint32_t *d_orb_cand = nullptr, *d_orb_cand_flat = nullptr, *d_orb_cand_count = nullptr, *d_lvl_ras = nullptr;
     float *d_lvl_resp = nullptr;
     int *d_lvl_n = nullptr;
-    int8_t *d_pattern0 = nullptr;  // the unrotated 31x31 test pattern
+    float *d_pattern0 = nullptr;   // the unrotated 31x31 test pattern as floats, [test of a byte][byte][x0 y0 x1 y1]
     uint32_t *d_orb_tab = nullptr;  // resize tables of all levels
     size_t orb_tab_cap = 0;
 

@@ -75,7 +75,7 @@ void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const
                        hipStream_t s);
 // rBRIEF-256 steered by each keypoint's angle, sampled on its level's blurred image
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
-                          const int *nkp, const int8_t *pattern, uint8_t *desc, hipStream_t s);
+                          const int *nkp, const float *pattern, uint8_t *desc, hipStream_t s);
 
 // ---- launchers (each enqueues on `s`, no sync) ---------------------------
 
