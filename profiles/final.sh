@@ -6,6 +6,8 @@ TAG=${1:-r01}
 R=$(pwd)
 bash $R/profiles/collect.sh $TAG
 cd $R
+bash $R/profiles/knn_counters.sh $TAG > /dev/null
+cd $R
 timeout -k 10 300 python3 bench.py > gpurun_out/${TAG}_bench_orb.json 2> gpurun_out/${TAG}_bench_orb.err
 timeout -k 10 300 python3 bench.py --detector fast > gpurun_out/${TAG}_bench_fast.json 2> gpurun_out/${TAG}_bench_fast.err
 timeout -k 10 200 python3 bench.py --matcher popcount --cpu-frames 0 --cpu-workers 0 > gpurun_out/${TAG}_bench_orb_popcount.json 2> gpurun_out/${TAG}_bench_popcount.err

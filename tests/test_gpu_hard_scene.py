@@ -1,0 +1,64 @@
+"""Parity on the scenes the benchmark's secondary legs use: frames with independently moving textured rectangles
+(about a third of the ratio-test survivors are outliers, so the 7-point RANSAC runs tens of iterations instead
+of a handful and the PnP RANSAC several rounds) and a flat wall seen at an angle (the planar branch of the pose
+refinement).  Same bars as the main pipeline tests: every list bit for bit, poses to the tolerance below."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+R_TOL = 1e-6  # rad
+T_TOL = 1e-6  # relative to |t| (mm)
+
+
+@pytest.mark.parametrize("scene", ["movers", "flat"])
+@pytest.mark.timeout(300)
+def test_hard_scene_streams_match_oracle(oracle, scene):
+    from oracle.pipeline import OracleStream
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F, N = 4, 6, 2000
+    cap = N + 64
+    if scene == "movers":
+        frames, depth, _ = synth.make_pingpong_batch(cam, S, F, seed=52000, channels=4, relief=2.0, movers=30,
+                                                     workers=4)
+    else:
+        frames, depth, _ = synth.make_pingpong_batch(cam, S, F, seed=72000, channels=4, relief=0.0,
+                                                     tilt=(0.08, -0.05), workers=4)
+    refs = [OracleStream(K, N, 20, orb_levels=8, feature_cap=cap) for _ in range(S)]
+    c = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=cap, max_batch=S * F)
+    try:
+        c.batch_configure(cam.width, cam.height, 4, n_streams=S, frames_per_stream=F, max_features=N,
+                          fast_threshold=20, camera=K, orb_levels=8)
+        c.batch_submit(frames, depth)
+        res = c.batch_wait()
+        n_pose, outl, iters = 0, [], []
+        for s in range(S):
+            for f in range(F):
+                b = s * F + f
+                ref = refs[s].process(frames[b], depth[b])
+                k, d = c.batch_features(b)
+                assert np.array_equal(k, ref["kps"]) and np.array_equal(d, ref["desc"]), (s, f)
+                assert res["n_ratio"][b] == ref["n_ratio"]
+                for which, name in ((0, "matches"), (1, "tracked"), (2, "valid")):
+                    m, p3 = c.batch_matches(b, which)
+                    assert np.array_equal(m, ref[name]), (s, f, name)
+                assert np.array_equal(p3, ref["pts3"])
+                assert bool(res["pnp_success"][b]) == ref["pnp_success"], (s, f)
+                if f > 0:
+                    outl.append(1.0 - res["f_inliers"][b] / max(1, res["n_ratio"][b]))
+                    iters.append(res["f_iters"][b])
+                if ref["pnp_success"]:
+                    n_pose += 1
+                    assert np.array_equal(c.batch_inliers(b), ref["inliers"])
+                    assert np.abs(res["rvec"][b] - ref["rvec"]).max() < R_TOL
+                    assert np.abs(res["tvec"][b] - ref["tvec"]).max() < T_TOL * max(1.0, np.linalg.norm(ref["tvec"]))
+        assert n_pose == S * (F - 1)
+        if scene == "movers":
+            # the scene is what it claims to be: many outliers, a long 7-point loop
+            assert np.mean(outl) > 0.2 and np.mean(iters) > 20
+    finally:
+        c.close()
