@@ -191,50 +191,52 @@ static void svd12_onesided(const double *Gcm, int rows, double *w, double *Vt)
     }
 }
 
-/* Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite 12 x 12 matrix (row-major)
- * by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
- * the pose refinement has one eigenvalue far below the others (the solution, at the noise level), so the
- * iteration converges in a few steps; what cv::SVD would return as the last row of V^T, up to sign. */
-static void smallest_eigvec12(const double *A, double *x)
+/* Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite n x n matrix (row-major,
+ * n <= 12) by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT
+ * system of the pose refinement (n = 12) and the normalised DLT of the homography (n = 9) have one eigenvalue far
+ * below the others (the solution, at the noise level; exactly zero for four points), so the iteration converges
+ * in a few steps; what cv::SVD would return as the last row of V^T, up to sign. */
+static void smallest_eigvec_n(const double *A, int n, double *x)
 {
     /* L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
      * number: for inverse iteration that only steepens the amplification of the wanted direction */
     double Lf[144], D[12];
     double dmax = 0;
-    for (int i = 0; i < 12; i++) dmax = fmax(dmax, fabs(A[i * 12 + i]));
+    for (int i = 0; i < n; i++) dmax = fmax(dmax, fabs(A[i * n + i]));
     const double tiny = dmax * 1e-30 + 1e-300;
-    for (int j = 0; j < 12; j++) {
-        double d = A[j * 12 + j];
-        for (int k = 0; k < j; k++) d -= Lf[j * 12 + k] * Lf[j * 12 + k] * D[k];
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= Lf[j * n + k] * Lf[j * n + k] * D[k];
         if (!(d > tiny)) d = tiny;
         D[j] = d;
-        for (int i = j + 1; i < 12; i++) {
-            double v = A[i * 12 + j];
-            for (int k = 0; k < j; k++) v -= Lf[i * 12 + k] * Lf[j * 12 + k] * D[k];
-            Lf[i * 12 + j] = v / d;
+        for (int i = j + 1; i < n; i++) {
+            double v = A[i * n + j];
+            for (int k = 0; k < j; k++) v -= Lf[i * n + k] * Lf[j * n + k] * D[k];
+            Lf[i * n + j] = v / d;
         }
     }
-    for (int i = 0; i < 12; i++) x[i] = 1.0 / sqrt(12.0);
+    for (int i = 0; i < n; i++) x[i] = 1.0 / sqrt((double)n);
     for (int it = 0; it < 12; it++) {
         double y[12];
-        for (int i = 0; i < 12; i++) {          /* L z = x */
+        for (int i = 0; i < n; i++) {          /* L z = x */
             double v = x[i];
-            for (int k = 0; k < i; k++) v -= Lf[i * 12 + k] * y[k];
+            for (int k = 0; k < i; k++) v -= Lf[i * n + k] * y[k];
             y[i] = v;
         }
-        for (int i = 0; i < 12; i++) y[i] /= D[i];
-        for (int i = 11; i >= 0; i--) {         /* L^T y = z */
+        for (int i = 0; i < n; i++) y[i] /= D[i];
+        for (int i = n - 1; i >= 0; i--) {     /* L^T y = z */
             double v = y[i];
-            for (int k = i + 1; k < 12; k++) v -= Lf[k * 12 + i] * y[k];
+            for (int k = i + 1; k < n; k++) v -= Lf[k * n + i] * y[k];
             y[i] = v;
         }
         double nrm = 0;
-        for (int i = 0; i < 12; i++) nrm += y[i] * y[i];
+        for (int i = 0; i < n; i++) nrm += y[i] * y[i];
         nrm = sqrt(nrm);
         if (!(nrm > 0) || !isfinite(nrm)) break;
-        for (int i = 0; i < 12; i++) x[i] = y[i] / nrm;
+        for (int i = 0; i < n; i++) x[i] = y[i] / nrm;
     }
 }
+static void smallest_eigvec12(const double *A, double *x) { smallest_eigvec_n(A, 12, x); }
 
 /* nearest rotation to a 3x3 matrix A (U V^T of its SVD), via the
  * eigen-decomposition of A^T A; a vanishing third singular value is
@@ -766,7 +768,7 @@ static int find_homography_ls(const float *M, const float *m, int n, double *H)
     if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON)
         return 0;
     smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
-    double LtL[81] = {0}, W[9], Vt[81];
+    double LtL[81] = {0}, H0[9];
     for (int i = 0; i < n; i++) {
         double x = (m[2 * i] - cmx) * smx, y = (m[2 * i + 1] - cmy) * smy;
         double X = (M[2 * i] - cMx) * sMx, Y = (M[2 * i + 1] - cMy) * sMy;
@@ -777,8 +779,9 @@ static int find_homography_ls(const float *M, const float *m, int n, double *H)
     }
     for (int j = 0; j < 9; j++)
         for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi_eig_desc(LtL, 9, W, Vt);
-    const double *H0 = Vt + 8 * 9;
+    /* [OCV-recall] cv::eigen(LtL) and its last eigenvector; here the same vector by inverse iteration (the
+     * result is divided by its last entry below, so sign and scale do not matter) */
+    smallest_eigvec_n(LtL, 9, H0);
     double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
     double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
     double T[9];

@@ -468,10 +468,13 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
 // tile (row r, column c) <-> image (y0 - 4 + r, x0 - 4 + c).
 //
 // Tile order is XCD-aware: consecutive blocks (grid x fastest) go to consecutive
-// XCDs, so blocks b and b+8 share an XCD (and its L2) and XCD
-// x = b % 8 walks down whole tile columns (frame*tiles_x + tx) congruent to x
-// mod 8; vertically adjacent tiles, which share 8 of their 24 staged rows, are
-// then processed by the same L2 at about the same time.
+// XCDs, so blocks b and b+8 share an XCD (and its L2).  By default XCD x = b % 8
+// works along whole tile rows (frame * tiles_y + ty congruent to x mod 8), one
+// tile after the other: a 128-px gray tile is one cache line wide, so its 4-px
+// apron reads both neighbouring lines, and with the row on one XCD those are
+// fetched into one L2 once.  VO_TILE_ORDER=cols selects the other order (whole
+// tile columns per XCD: vertically adjacent tiles share 8 of their 40 staged
+// rows), which fetches about twice as much and takes the same time.
 // (col = frame * tiles_x + tile column, ty = tile row: which tile this block processes)
 template <int CN>
 __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int width, int height, int src_stride,
@@ -767,7 +770,8 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     FE_STAMP(9);
 }
 
-// grid: x = 8 * tile row + XCD slot, y = group of eight tile columns (frame * tiles_x + tx)
+// grid (column order, inv_tiles_y == 0): x = 8 * tile row + XCD slot, y = group of eight tile columns
+// (frame * tiles_x + tx); row order: see the body
 template <int CN>
 __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
                                                          int height, int src_stride,

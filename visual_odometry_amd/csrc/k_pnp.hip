@@ -788,128 +788,123 @@ __device__ void block_reduce(PrShared &S, double (&v)[NV])
 // cvFindExtrinsicCameraParams2 (cv::solvePnP, SOLVEPNP_ITERATIVE)
 // ---------------------------------------------------------------------
 
-// cyclic Jacobi eigen-decomposition of a symmetric 9x9 matrix; returns the unit
-// eigenvector of the smallest eigenvalue.  One lane, arrays in private memory:
-// only planar frames come here.
-__device__ __noinline__ void eig9_smallest(const double *Ain, double *vec)
-{
-    constexpr int N = 9;
-    double A[N * N], V[N * N];
-    for (int i = 0; i < N * N; i++) { A[i] = Ain[i]; V[i] = (i % (N + 1) == 0) ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0, diag = 0;
-        for (int i = 0; i < N; i++)
-            for (int j = 0; j < N; j++) {
-                if (i != j) off += A[i * N + j] * A[i * N + j];
-                else diag += A[i * N + j] * A[i * N + j];
-            }
-        if (off <= 1e-30 * diag || off == 0) break;
-        for (int p = 0; p < N - 1; p++)
-            for (int q = p + 1; q < N; q++) {
-                const double apq = A[p * N + q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q * N + q] - A[p * N + p]) / (2 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(t * t + 1), sn = t * c;
-                for (int k = 0; k < N; k++) {
-                    const double akp = A[k * N + p], akq = A[k * N + q];
-                    A[k * N + p] = c * akp - sn * akq;
-                    A[k * N + q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < N; k++) {
-                    const double apk = A[p * N + k], aqk = A[q * N + k];
-                    A[p * N + k] = c * apk - sn * aqk;
-                    A[q * N + k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < N; k++) {
-                    const double vkp = V[k * N + p], vkq = V[k * N + q];
-                    V[k * N + p] = c * vkp - sn * vkq;
-                    V[k * N + q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    // the last of the eigenvalues in descending order (ties: the one a stable exchange sort leaves last)
-    int order[N];
-    for (int i = 0; i < N; i++) order[i] = i;
-    for (int i = 0; i < N; i++)
-        for (int j = i + 1; j < N; j++)
-            if (A[order[j] * N + order[j]] > A[order[i] * N + order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    const int m = order[N - 1];
-    for (int k = 0; k < N; k++) vec[k] = V[k * N + m];
-}
-
-// Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite 12 x 12 matrix (row-major)
+// Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite N x N matrix (row-major)
 // by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
-// the pose refinement has one eigenvalue far below the others (the solution, at the noise level), so the
-// iteration converges in a few steps.  One lane; a tenth of the cycles of a 12-column Jacobi decomposition.
-__device__ __noinline__ void smallest_eigvec12(const double *A, double *x)
+// the pose refinement (N = 12) and the normalised DLT of the homography (N = 9) have one eigenvalue far below the
+// others (the solution, at the noise level; exactly zero for four points), so the iteration converges in a few
+// steps.  One lane, everything unrolled into registers; a tenth of the cycles of a Jacobi decomposition.
+template <int N>
+__device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
 {
     // L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
     // number: for inverse iteration that only steepens the amplification of the wanted direction
-    double Lf[144], D[12];
+    double Lf[N * N], D[N];
     double dmax = 0;
-    for (int i = 0; i < 12; i++) dmax = fmax(dmax, fabs(A[i * 12 + i]));
+#pragma unroll
+    for (int i = 0; i < N; i++) dmax = fmax(dmax, fabs(A[i * N + i]));
     const double tiny = dmax * 1e-30 + 1e-300;
-    for (int j = 0; j < 12; j++) {
-        double d = A[j * 12 + j];
-        for (int k = 0; k < j; k++) d -= Lf[j * 12 + k] * Lf[j * 12 + k] * D[k];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[j * N + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= Lf[j * N + k] * Lf[j * N + k] * D[k];
         if (!(d > tiny)) d = tiny;
         D[j] = d;
-        for (int i = j + 1; i < 12; i++) {
-            double v = A[i * 12 + j];
-            for (int k = 0; k < j; k++) v -= Lf[i * 12 + k] * Lf[j * 12 + k] * D[k];
-            Lf[i * 12 + j] = v / d;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double v = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= Lf[i * N + k] * Lf[j * N + k] * D[k];
+            Lf[i * N + j] = v / d;
         }
     }
-    for (int i = 0; i < 12; i++) x[i] = 1.0 / sqrt(12.0);
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] = 1.0 / sqrt((double)N);
     for (int it = 0; it < 12; it++) {
-        double y[12];
-        for (int i = 0; i < 12; i++) {          // L z = x
+        double y[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {          // L z = x
             double v = x[i];
-            for (int k = 0; k < i; k++) v -= Lf[i * 12 + k] * y[k];
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= Lf[i * N + k] * y[k];
             y[i] = v;
         }
-        for (int i = 0; i < 12; i++) y[i] /= D[i];
-        for (int i = 11; i >= 0; i--) {         // L^T y = z
+#pragma unroll
+        for (int i = 0; i < N; i++) y[i] /= D[i];
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) {     // L^T y = z
             double v = y[i];
-            for (int k = i + 1; k < 12; k++) v -= Lf[k * 12 + i] * y[k];
+#pragma unroll
+            for (int k = i + 1; k < N; k++) v -= Lf[k * N + i] * y[k];
             y[i] = v;
         }
         double nrm = 0;
-        for (int i = 0; i < 12; i++) nrm += y[i] * y[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) nrm += y[i] * y[i];
         nrm = sqrt(nrm);
         if (!(nrm > 0) || !isfinite(nrm)) break;
-        for (int i = 0; i < 12; i++) x[i] = y[i] / nrm;
+#pragma unroll
+        for (int i = 0; i < N; i++) x[i] = y[i] / nrm;
     }
 }
+__device__ __noinline__ void smallest_eigvec12(const double *A, double *x) { smallest_eigvec<12>(A, x); }
+__device__ __noinline__ void smallest_eigvec9(const double *A, double *x) { smallest_eigvec<9>(A, x); }
 
-// 8x8 solve, Gaussian elimination with partial pivoting; false when singular
+// 8x8 solve, Gaussian elimination with partial pivoting (the first row of largest magnitude); false when
+// singular.  One lane; every index is a compile-time constant (the row exchange is a chain of predicated
+// swaps), so the matrix lives in registers, not in scratch memory.
 __device__ __noinline__ bool solve_gauss8(const double *Ain, const double *bin, double *x)
 {
     constexpr int n = 8;
     double A[64], b[8];
+#pragma unroll
     for (int i = 0; i < 64; i++) A[i] = Ain[i];
+#pragma unroll
     for (int i = 0; i < 8; i++) b[i] = bin[i];
+    bool ok = true;
+#pragma unroll
     for (int k = 0; k < n; k++) {
         int piv = k;
-        for (int i = k + 1; i < n; i++)
-            if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
-        if (A[piv * n + k] == 0) return false;
-        if (piv != k) {
-            for (int j = 0; j < n; j++) { const double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
-            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
-        }
+        double best = fabs(A[k * n + k]);
+#pragma unroll
         for (int i = k + 1; i < n; i++) {
-            const double f = A[i * n + k] / A[k * n + k];
+            const double v = fabs(A[i * n + k]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (best == 0) ok = false;
+#pragma unroll
+        for (int i = k + 1; i < n; i++) {
+            const bool sw = piv == i;
+#pragma unroll
+            for (int j = k; j < n; j++) {
+                const double u = A[k * n + j], w = A[i * n + j];
+                A[k * n + j] = sw ? w : u;
+                A[i * n + j] = sw ? u : w;
+            }
+            const double u = b[k], w = b[i];
+            b[k] = sw ? w : u;
+            b[i] = sw ? u : w;
+        }
+        const double pivot = ok ? A[k * n + k] : 1.0;
+#pragma unroll
+        for (int i = k + 1; i < n; i++) {
+            const double f = A[i * n + k] / pivot;
+#pragma unroll
             for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
             b[i] -= f * b[k];
         }
     }
+    if (!ok) return false;
+    double xs[8];
+#pragma unroll
     for (int k = n - 1; k >= 0; k--) {
         double sm = b[k];
-        for (int j = k + 1; j < n; j++) sm -= A[k * n + j] * x[j];
-        x[k] = sm / A[k * n + k];
+#pragma unroll
+        for (int j = k + 1; j < n; j++) sm -= A[k * n + j] * xs[j];
+        xs[k] = sm / A[k * n + k];
     }
+#pragma unroll
+    for (int k = 0; k < n; k++) x[k] = xs[k];
     return true;
 }
 
@@ -1055,7 +1050,7 @@ __device__ __noinline__ void planar_pose_init(PrShared &S, const float *obj, con
             int q = 0;
             for (int a = 0; a < 9; a++)
                 for (int bb = a; bb < 9; bb++, q++) LtL[a * 9 + bb] = LtL[bb * 9 + a] = S.sums[q];
-            eig9_smallest(LtL, H0);
+            smallest_eigvec9(LtL, H0);
             const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
             const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
             for (int i = 0; i < 3; i++)
