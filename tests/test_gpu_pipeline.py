@@ -291,6 +291,34 @@ def test_batch_pipeline_full_orb(ctx, oracle):
                     assert ref["pnp_success"] and len(ref["matches"]) > 100
 
 
+@pytest.mark.parametrize("shape,levels", [((200, 120), 0), ((30, 300), 0), ((260, 126), 3), ((330, 128), 4)])
+def test_batch_of_frames_one_tile_wide_or_high(ctx, oracle, shape, levels):
+    """Several frames per launch whose tile grid has a single column (width <= 128) or a single row (height <= 32):
+    the block -> (frame, tile) maps divide by 1 there.  Features of every frame against the oracle."""
+    h, w = shape
+    big = synth.make_sequence(synth.CONFIG_CAMERAS["hd720"], 1, seed=h * 7 + w, channels=1)["frames"][0]
+    S = 6
+    frames = np.stack([np.ascontiguousarray(big[20 + 37 * s:20 + 37 * s + h, 60 + 101 * s:60 + 101 * s + w])
+                       for s in range(S)])
+    depth = np.full((S, h, w), 3000.0, np.float32)
+    ctx.batch_configure(w, h, 1, n_streams=S, frames_per_stream=1, max_features=400, fast_threshold=20,
+                        camera=(500.0, 500.0, w / 2, h / 2), orb_levels=levels)
+    ctx.batch_submit(frames, depth)
+    ctx.batch_wait()
+    total = 0
+    for s in range(S):
+        if levels:
+            k_ref, d_ref = oracle.orb_detect(frames[s], 400, 1.2, levels, 20)
+            k_ref, d_ref = k_ref[:ctx.max_features], d_ref[:ctx.max_features]
+        else:
+            k_ref, d_ref = oracle.detect(frames[s], 400, 20)
+        k, d = ctx.batch_features(s)
+        assert np.array_equal(k, k_ref) and np.array_equal(d, d_ref), s
+        total += len(k)
+    if h > 70 and w > 70:
+        assert total > 50  # the frames are large enough to hold key points inside the 31-px border
+
+
 @pytest.mark.parametrize("levels", [0, 8])
 def test_batch_is_reproducible_run_to_run(ctx, levels):
     """The same batch twice (streams reset in between): every output identical bit for bit, poses included --

@@ -499,7 +499,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     if (col >= batch * tiles_x) return;
     FeTile tile;
     {
-        tile.frame = (int)__umulhi((uint32_t)col, inv_tiles_x);  // col / tiles_x (exact: host-side magic number)
+        tile.frame = (int)magic_div((uint32_t)col, inv_tiles_x);  // col / tiles_x
         tile.x0 = (col - tile.frame * tiles_x) * FE_TW;
         tile.y0 = ty * FE_TH;
         tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
@@ -770,7 +770,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     FE_STAMP(9);
 }
 
-// grid (column order, inv_tiles_y == 0): x = 8 * tile row + XCD slot, y = group of eight tile columns
+// grid (column order, by_rows == 0): x = 8 * tile row + XCD slot, y = group of eight tile columns
 // (frame * tiles_x + tx); row order: see the body
 template <int CN>
 __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restrict__ src, int width,
@@ -779,9 +779,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          PlaneBatch score, PlaneBatch blur, int thr,
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
                                                          uint32_t *__restrict__ tile_count, int batch,
-                                                         uint32_t inv_tiles_x, int margin, uint32_t inv_tiles_y)
+                                                         uint32_t inv_tiles_x, int margin, uint32_t inv_tiles_y,
+                                                         int by_rows)
 {
-    if (inv_tiles_y == 0) {
+    if (!by_rows) {
         fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
                     batch, inv_tiles_x, margin, (int)(blockIdx.y * 8 + (blockIdx.x & 7)), (int)(blockIdx.x >> 3));
         return;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
     const int tiles_x = (width + FE_TW - 1) / FE_TW, tiles_y = (height + FE_TH - 1) / FE_TH;
     const int row = (int)(blockIdx.y * 8 + (blockIdx.x & 7));
     if (row >= batch * tiles_y) return;
-    const int frame = (int)__umulhi((uint32_t)row, inv_tiles_y);
+    const int frame = (int)magic_div((uint32_t)row, inv_tiles_y);
     fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
                 batch, inv_tiles_x, margin, frame * tiles_x + (int)(blockIdx.x >> 3), row - frame * tiles_y);
 }
@@ -828,16 +829,16 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend_levels(FeLevels t, int 
     const int local = g - L.first_group;
     if (t.by_rows) {
         const int tiles_x = (L.width + FE_TW - 1) / FE_TW;
-        const int rg = (int)__umulhi((uint32_t)local, L.inv_tiles_x);  // local / tiles_x
+        const int rg = (int)magic_div((uint32_t)local, L.inv_tiles_x);  // local / tiles_x
         const int tx = local - rg * tiles_x, row = rg * 8 + xcd;
         if (row >= batch * L.tiles_y) return;
-        const int frame = (int)__umulhi((uint32_t)row, L.inv_tiles_y);
+        const int frame = (int)magic_div((uint32_t)row, L.inv_tiles_y);
         fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0},
                    PlaneBatch{nullptr, 0, 0}, PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count,
                    batch, L.inv_tiles_x, margin, frame * tiles_x + tx, row - frame * L.tiles_y, t.unused_edge);
         return;
     }
-    const int cg = (int)__umulhi((uint32_t)local, L.inv_tiles_y);  // local / tiles_y
+    const int cg = (int)magic_div((uint32_t)local, L.inv_tiles_y);  // local / tiles_y
     const int ty = local - cg * L.tiles_y;
     fe_tile<1>(L.src, L.width, L.height, L.pitch, t.frame_stride, PlaneBatch{nullptr, 0, 0}, PlaneBatch{nullptr, 0, 0},
                PlaneBatch{L.blur, L.pitch, t.frame_stride}, thr, c, L.cand, L.tile_count, batch, L.inv_tiles_x, margin,
@@ -868,23 +869,21 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     const bool by_rows = tile_order_by_rows();
     dim3 grid(8 * tiles_y, (ncols + 7) / 8);
     if (by_rows) grid = dim3(8 * tiles_x, (tiles_y * batch + 7) / 8);
-    // floor(col / tiles_x) == umulhi(col, inv) for col * tiles_x < 2^32
-    const uint32_t inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
-    const uint32_t inv_tiles_y = by_rows ? (uint32_t)(0x100000000ull / (uint32_t)tiles_y) + 1u : 0u;
+    const uint32_t inv_tiles_x = magic_inv(tiles_x), inv_tiles_y = magic_inv(tiles_y);
     threshold = threshold < 0 ? 0 : (threshold > 255 ? 255 : threshold);
     margin = margin < 3 ? 3 : margin;  // cv::FAST itself never evaluates the outer 3 pixels
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y);
+                           inv_tiles_y, by_rows ? 1 : 0);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y);
+                           inv_tiles_y, by_rows ? 1 : 0);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y);
+                           inv_tiles_y, by_rows ? 1 : 0);
 }
 
 void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t *pyr, uint8_t *pyr_blur,
@@ -908,8 +907,8 @@ void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t 
         L.cand = cand + P.cand_off;
         L.tile_count = tile_count + P.count_off;
         L.width = P.w; L.height = P.h; L.pitch = P.pitch; L.tiles_y = tiles_y;
-        L.inv_tiles_x = (uint32_t)(0x100000000ull / (uint32_t)tiles_x) + 1u;
-        L.inv_tiles_y = (uint32_t)(0x100000000ull / (uint32_t)tiles_y) + 1u;
+        L.inv_tiles_x = magic_inv(tiles_x);
+        L.inv_tiles_y = magic_inv(tiles_y);
         L.first_group = groups;
         groups += t.by_rows ? tiles_x * ((tiles_y * batch + 7) / 8) : tiles_y * ((tiles_x * batch + 7) / 8);
     }

@@ -28,15 +28,23 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 struct FrameBlock {
     int frame, block;
 };
-__device__ __forceinline__ FrameBlock frame_block(int per_frame, int batch)
+struct FrameGrid {
+    int per_frame, batch;
+    uint32_t inv;  // magic_inv(per_frame)
+};
+inline FrameGrid frame_grid(int per_frame, int batch)
 {
-    if (batch & 7) {
-        const int frame = (int)blockIdx.x / per_frame;
-        return FrameBlock{frame, (int)blockIdx.x - frame * per_frame};
+    return FrameGrid{per_frame, batch, magic_inv(per_frame)};
+}
+__device__ __forceinline__ FrameBlock frame_block(const FrameGrid &g)
+{
+    if (g.batch & 7) {
+        const int frame = (int)magic_div(blockIdx.x, g.inv);
+        return FrameBlock{frame, (int)blockIdx.x - frame * g.per_frame};
     }
     const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
-    const int group = slot / per_frame;
-    return FrameBlock{group * 8 + xcd, slot - group * per_frame};
+    const int group = (int)magic_div((uint32_t)slot, g.inv);
+    return FrameBlock{group * 8 + xcd, slot - group * g.per_frame};
 }
 
 // ------------------------------------------------------------------ resize
@@ -44,7 +52,6 @@ __device__ __forceinline__ FrameBlock frame_block(int per_frame, int batch)
 constexpr int RZ_TW = 128, RZ_TH = 32, RZ_THREADS = 256;
 constexpr int RZ_FP = 288;    // LDS footprint row pitch (bytes): scale <= 2 plus alignment slack
 constexpr int RZ_FROWS = 68;  // footprint rows
-constexpr int RZ_STAGE = (RZ_FROWS * (RZ_FP / 16) + RZ_THREADS - 1) / RZ_THREADS;  // 16-byte staging loads per thread
 constexpr int RZ_SPAN = 6;    // largest source distance between the first and last of a thread's four columns
 static_assert(RZ_TH == kResizeRowPad, "row tables are padded to whole resize tiles");
 
@@ -58,16 +65,19 @@ static_assert(RZ_TH == kResizeRowPad, "row tables are padded to whole resize til
 // funnel-shifted once so that the first column's left tap sits at byte 0, then
 // one v_perm_b32 with a per-lane selector (set up once per thread) extracts each
 // column's tap pair and one v_dot2_u32_u16 weighs it.
+// (A block that walks down a strip of four tiles and prefetches the next footprint into registers while it
+// computes -- 78 registers, two barriers per tile -- was slower, 0.78 against 0.70 ms for the seven levels of 512
+// HD720 frames: eight independent blocks per CU overlap loads and arithmetic better than one block does itself.)
 __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
                                                             int dh, const uint32_t *__restrict__ xtab,
                                                             const uint32_t *__restrict__ ytab, int tiles_x,
-                                                            int tiles_y, int batch)
+                                                            uint32_t inv_tiles_x, FrameGrid fg)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RZ_FROWS * RZ_FP + 16];
 
     const int tid = threadIdx.x;
-    const FrameBlock fb = frame_block(tiles_x * tiles_y, batch);  // a frame's tiles in raster order on one XCD
-    const int ty = fb.block / tiles_x, tx = fb.block - ty * tiles_x;
+    const FrameBlock fb = frame_block(fg);  // a frame's tiles in raster order on one XCD
+    const int ty = (int)magic_div((uint32_t)fb.block, inv_tiles_x), tx = fb.block - ty * tiles_x;
     const int x0 = tx * RZ_TW, y0 = ty * RZ_TH, f = fb.frame;
     // block-uniform footprint (tables are padded to whole tiles with their last entry)
     const int sx_lo = (int)(xtab[x0] & 0xffffu) & ~15;
@@ -78,23 +88,27 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
     const int cols16 = (sx_hi - sx_lo) / 16 + 1, rows = sy_hi - sy_lo + 1;
     const uint8_t *sp = src.base + f * src.plane_stride + (size_t)sy_lo * src.pitch + sx_lo;
     {
-        const int n16 = rows * cols16;
-        uint4 piece[RZ_STAGE];
-        int at[RZ_STAGE];
+        // 32 lanes per footprint row (at most RZ_FP / 16 = 18 pieces: the others repeat the last one and store
+        // nothing), eight rows per step: one address add per load, no division
+        static_assert(RZ_FP / 16 <= 32 && RZ_THREADS == 256, "a footprint row fits 32 lanes, eight rows per step");
+        constexpr int STEPS = (RZ_FROWS + 7) / 8;
+        const int c = tid & 31, r0 = tid >> 5;
+        const bool col_ok = c < cols16;
+        const uint8_t *p = sp + (size_t)r0 * src.pitch + 16 * min(c, cols16 - 1);
+        const size_t step = (size_t)8 * src.pitch;
+        uint4 piece[STEPS];
 #pragma unroll
-        for (int u = 0; u < RZ_STAGE; u++) {  // all loads in flight before the first LDS write
+        for (int u = 0; u < STEPS; u++) {  // all loads in flight before the first LDS write
             piece[u] = make_uint4(0, 0, 0, 0);
-            at[u] = 0;
-            if (u * RZ_THREADS < n16) {  // block-uniform; lanes past the end re-read the last piece
-                const int i = min(tid + u * RZ_THREADS, n16 - 1);
-                const int r = i / cols16, c = i - r * cols16;
-                piece[u] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * src.pitch + c * 16);
-                at[u] = r * RZ_FP + c * 16;
+            if (u * 8 < rows) {  // block-uniform; rows past the footprint re-read its last row
+                piece[u] = *reinterpret_cast<const uint4 *>(r0 + u * 8 < rows ? p : sp + (size_t)(rows - 1) * src.pitch);
+                p += step;
             }
         }
+        uint8_t *q = &s_src[r0 * RZ_FP + 16 * c];
 #pragma unroll
-        for (int u = 0; u < RZ_STAGE; u++)
-            if (tid + u * RZ_THREADS < n16) *reinterpret_cast<uint4 *>(&s_src[at[u]]) = piece[u];
+        for (int u = 0; u < STEPS; u++)
+            if (col_ok && r0 + u * 8 < rows) *reinterpret_cast<uint4 *>(q + u * 8 * RZ_FP) = piece[u];
     }
     // this thread's four columns
     const int lx = (tid & 31) * 4;
@@ -117,13 +131,10 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
     __syncthreads();
 
     uint8_t *dp = dst.base + f * dst.plane_stride;
-    const int gx = x0 + lx;
-    if (gx >= dw) return;
     const uint8_t *col = &s_src[base - sx_lo];
+    uint32_t out[RZ_TH / 8];  // this thread's four columns of its four rows
 #pragma unroll
     for (int k = 0; k < RZ_TH / 8; k++) {
-        const int gy = y0 + (tid >> 5) + k * 8;
-        if (gy >= dh) continue;
         const uint32_t ye = yes[k];
         const int yo = (int)(ye & 0xffffu);
         const uint32_t wy1 = ye >> 16;
@@ -144,8 +155,28 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
         }
         // results are bits 16..23 of each v (v < 2^24)
         const uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), hi = __builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u);
-        *reinterpret_cast<uint32_t *>(dp + (size_t)gy * dst.pitch + gx) = lo | (hi << 16);  // pitch is padded
+        out[k] = lo | (hi << 16);
     }
+    // 4 x 4 transpose inside each group of four lanes (16 adjacent columns): lane l of the group ends up with the
+    // 16 bytes of the group's row l and stores them at once
+    static_assert(RZ_TH / 8 == 4, "four rows per thread, four lanes per 16-byte store");
+    {
+        const bool b0 = tid & 1, b1 = tid & 2;
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {  // rows (k, k+1) between lanes l and l ^ 1
+            const uint32_t recv = __shfl_xor(b0 ? out[k] : out[k + 1], 1);
+            if (b0) out[k] = recv; else out[k + 1] = recv;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {     // rows (k, k+2) between lanes l and l ^ 2
+            const uint32_t recv = __shfl_xor(b1 ? out[k] : out[k + 2], 2);
+            if (b1) out[k] = recv; else out[k + 2] = recv;
+        }
+    }
+    const int gx = x0 + (lx & ~15);                   // first column of the group
+    const int gy = y0 + (tid >> 5) + (tid & 3) * 8;   // the row this lane stores
+    if (gx < dw && gy < dh)                           // pitch is padded: the last group may run past the width
+        *reinterpret_cast<uint4 *>(dp + (size_t)gy * dst.pitch + gx) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // ------------------------------------------------- per-level keypoint ranking
@@ -446,10 +477,10 @@ __global__ __launch_bounds__(OF_THREADS) void k_orb_finish(OrbPlan plan, const u
                                                           const float *__restrict__ lvl_resp,
                                                           const int *__restrict__ lvl_n, vo_kp *__restrict__ kps,
                                                           int kp_stride, int kp_cap, int *__restrict__ nkp,
-                                                          int blocks_per_frame, int batch)
+                                                          FrameGrid fg)
 {
     __shared__ uint32_t s_mask[16][OF_LANES];
-    const FrameBlock fb = frame_block(blocks_per_frame, batch);
+    const FrameBlock fb = frame_block(fg);
     const int f = fb.frame, gl = threadIdx.x & (OF_LANES - 1);
     const int i = fb.block * OF_KPB + (threadIdx.x >> 3);
     if (threadIdx.x < 16 * OF_LANES) {
@@ -546,12 +577,12 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
                                                       const vo_kp *__restrict__ kps, int kp_stride,
                                                       const int *__restrict__ nkp,
                                                       const float *__restrict__ pattern,
-                                                      uint8_t *__restrict__ desc, int blocks_per_frame, int batch)
+                                                      uint8_t *__restrict__ desc, FrameGrid fg)
 {
     __shared__ float4 s_pat[256];  // [test of a byte][byte]: x0 y0 x1 y1
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
     __shared__ float s_cs[8][2];
-    const FrameBlock fb = frame_block(blocks_per_frame, batch);
+    const FrameBlock fb = frame_block(fg);
     s_pat[threadIdx.x] = reinterpret_cast<const float4 *>(pattern)[threadIdx.x];
     const int f = fb.frame;
     const int g = threadIdx.x >> 5, k = fb.block * 8 + g;
@@ -714,7 +745,8 @@ void launch_resize_exact(PlaneBatch src, int sw, int sh, PlaneBatch dst, int dw,
 {
     const int tiles_x = (dw + RZ_TW - 1) / RZ_TW, tiles_y = (dh + RZ_TH - 1) / RZ_TH;
     hipLaunchKernelGGL(k_resize_exact, dim3((unsigned)(tiles_x * tiles_y * batch)), dim3(RZ_THREADS), 0, s, src, sw,
-                       sh, dst, dw, dh, xtab, ytab, tiles_x, tiles_y, batch);
+                       sh, dst, dw, dh, xtab, ytab, tiles_x, magic_inv(tiles_x),
+                       frame_grid(tiles_x * tiles_y, batch));
 }
 
 void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *cand,
@@ -731,7 +763,7 @@ void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 {
     const int per_frame = (kp_stride + OF_KPB - 1) / OF_KPB;
     hipLaunchKernelGGL(k_orb_finish, dim3((unsigned)(per_frame * batch)), dim3(OF_THREADS), 0, s, plan, pyr, lvl_ras,
-                       lvl_resp, lvl_n, kps, kp_stride, kp_cap, nkp, per_frame, batch);
+                       lvl_resp, lvl_n, kps, kp_stride, kp_cap, nkp, frame_grid(per_frame, batch));
 }
 
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
@@ -739,7 +771,7 @@ void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blu
 {
     const int per_frame = (kp_stride + 7) / 8;
     hipLaunchKernelGGL(k_brief_steered, dim3((unsigned)(per_frame * batch)), dim3(256), 0, s, plan, pyr_blur, kps,
-                       kp_stride, nkp, pattern, desc, per_frame, batch);
+                       kp_stride, nkp, pattern, desc, frame_grid(per_frame, batch));
 }
 
 }  // namespace vo

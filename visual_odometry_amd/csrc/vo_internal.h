@@ -21,6 +21,11 @@ inline int tiles_of(int w, int h) { return ((w + kTileW - 1) / kTileW) * ((h + k
 constexpr int kOrbMaxLevels = 8;   // pyramid levels of the full ORB detector
 constexpr int kOrbLevelCap = 2048; // keypoints one level can contribute
 
+// floor(x / d) without a run-time division: umulhi(x, magic_inv(d)), exact while x * d < 2^32.  d = 1 has no
+// 32-bit magic number and is encoded as 0.
+inline uint32_t magic_inv(int d) { return d > 1 ? (uint32_t)(0x100000000ull / (uint32_t)d) + 1u : 0u; }
+__device__ __forceinline__ uint32_t magic_div(uint32_t x, uint32_t inv) { return inv ? __umulhi(x, inv) : x; }
+
 // gray conversion weights (B, G, R, shift)
 struct GrayCoeffs {
     int b, g, r, shift;
