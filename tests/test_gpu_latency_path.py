@@ -1,0 +1,126 @@
+"""The batch-of-1 latency path the FrameProcessor facade uses -- packed output (one D2H copy per frame), HIP graph
+replay of the kernel chain, pinned host buffers -- must return exactly what the ordinary path returns: the same
+streams are run with the options off and on and compared record by record, across replays, a re-configuration
+(new geometry: the graph is captured again) and both detectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, cam, seqs, F, NB, levels, packed, graph, channels=4, pinned=None):
+    """Every frame of NB launches of S streams x F frames; returns per (launch, batch entry) a dict of everything."""
+    S = len(seqs)
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    ctx.batch_configure(cam.width, cam.height, channels, n_streams=S, frames_per_stream=F, max_features=600,
+                        fast_threshold=20, camera=K, orb_levels=levels)
+    ctx.batch_set_packed_output(packed)
+    ctx.batch_set_graph(graph)
+    out = []
+    for nb in range(NB):
+        frames = np.stack([seqs[s]["frames"][nb * F + f] for s in range(S) for f in range(F)])
+        depth = np.stack([seqs[s]["depth"][nb * F + f] for s in range(S) for f in range(F)])
+        if pinned is not None:
+            fb, db = pinned
+            np.copyto(fb, frames)
+            np.copyto(db, depth)
+            frames, depth = fb, db
+        ctx.batch_submit(frames, depth)
+        res = ctx.batch_wait()
+        for b in range(S * F):
+            if packed:
+                p = ctx.batch_packed(b)
+                assert p["result"].tobytes() == res[b].tobytes()
+                rec = {k: p[k] for k in ("kps", "desc", "matches", "tracked", "valid", "pts3", "inliers")}
+            else:
+                k, d = ctx.batch_features(b)
+                m, _ = ctx.batch_matches(b, 0)
+                t, _ = ctx.batch_matches(b, 1)
+                v, p3 = ctx.batch_matches(b, 2)
+                rec = {"kps": k, "desc": d, "matches": m, "tracked": t, "valid": v, "pts3": p3,
+                       "inliers": ctx.batch_inliers(b) if res["pnp_success"][b] else np.zeros(0, np.int32)}
+            rec["result"] = res[b].copy()
+            out.append(rec)
+    return out
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x["result"].tobytes() == y["result"].tobytes(), i
+        for k in ("kps", "desc", "matches", "tracked", "valid", "pts3"):
+            assert np.array_equal(x[k], y[k]), (i, k)
+        if x["result"]["pnp_success"]:
+            assert np.array_equal(x["inliers"], y["inliers"]), i
+
+
+@pytest.mark.parametrize("levels", [0, 4])
+def test_packed_output_and_graph_replay_equal_the_plain_path(ctx, levels):
+    cam = synth.CONFIG_CAMERAS["vga"]
+    S, F, NB = 2, 2, 3
+    seqs = [synth.make_sequence(cam, F * NB, seed=4100 + s, channels=4) for s in range(S)]
+    plain = _run(ctx, cam, seqs, F, NB, levels, packed=False, graph=False)
+    assert sum(int(r["result"]["pnp_success"]) for r in plain) == S * (F * NB - 1)
+    ctx.batch_reset()
+    _same(_run(ctx, cam, seqs, F, NB, levels, packed=True, graph=False), plain)
+    ctx.batch_reset()
+    _same(_run(ctx, cam, seqs, F, NB, levels, packed=False, graph=True), plain)
+    ctx.batch_reset()
+    _same(_run(ctx, cam, seqs, F, NB, levels, packed=True, graph=True), plain)
+
+
+def test_graph_is_captured_again_after_a_new_geometry(ctx):
+    """One context, graph on throughout: VGA, then a smaller gray geometry, then VGA again -- each segment equals the
+    plain path on a fresh stream state."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    seqs = [synth.make_sequence(cam, 4, seed=4300, channels=4)]
+    small = synth.Camera(width=320, height=200, fx=300.0, fy=300.0, cx=160.0, cy=100.0)
+    gray = [{"frames": np.ascontiguousarray(seqs[0]["frames"][:, 100:300, 200:520, 1]),
+             "depth": np.ascontiguousarray(seqs[0]["depth"][:, 100:300, 200:520])}]
+    ref_a = _run(ctx, cam, seqs, 1, 4, 0, packed=False, graph=False)
+    ref_b = _run(ctx, small, gray, 1, 4, 0, packed=False, graph=False, channels=1)
+    _same(_run(ctx, cam, seqs, 1, 4, 0, packed=True, graph=True), ref_a)
+    _same(_run(ctx, small, gray, 1, 4, 0, packed=True, graph=True, channels=1), ref_b)
+    _same(_run(ctx, cam, seqs, 1, 4, 0, packed=True, graph=True), ref_a)
+
+
+def test_pinned_host_buffers(ctx):
+    """Frames and depth handed over in memory from vo_host_alloc: same results as from ordinary numpy arrays."""
+    from visual_odometry_amd import capi
+    lib = capi.load()
+    cam = synth.CONFIG_CAMERAS["vga"]
+    seqs = [synth.make_sequence(cam, 3, seed=4500, channels=4)]
+    nf, nd = cam.height * cam.width * 4, cam.height * cam.width * 4
+    pf, pd = lib.vo_host_alloc(nf), lib.vo_host_alloc(nd)
+    assert pf and pd
+    try:
+        fb = np.ctypeslib.as_array((C.c_uint8 * nf).from_address(pf)).reshape(1, cam.height, cam.width, 4)
+        db = np.ctypeslib.as_array((C.c_float * (nd // 4)).from_address(pd)).reshape(1, cam.height, cam.width)
+        ref = _run(ctx, cam, seqs, 1, 3, 0, packed=False, graph=False)
+        _same(_run(ctx, cam, seqs, 1, 3, 0, packed=True, graph=True, pinned=(fb, db)), ref)
+    finally:
+        lib.vo_host_free(pf)
+        lib.vo_host_free(pd)
+
+
+def test_packed_output_is_refused_for_large_batches():
+    """The packed block is meant for the latency path: batch x (128 + 156 x feature capacity) bytes above 32 MiB is
+    an argument error, and the context keeps working without it."""
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    c = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=2064, max_batch=128)
+    try:
+        c.batch_configure(cam.width, cam.height, 1, n_streams=128, frames_per_stream=1, max_features=2000,
+                          camera=(cam.fx, cam.fy, cam.cx, cam.cy))
+        with pytest.raises(capi.VoError):
+            c.batch_set_packed_output(True)
+        g = synth.make_sequence(cam, 1, seed=9, channels=1)["frames"][0]
+        c.batch_submit(np.stack([g] * 128), None)
+        res = c.batch_wait()
+        assert (res["n_keypoints"] == res["n_keypoints"][0]).all() and res["n_keypoints"][0] > 100
+    finally:
+        c.close()
