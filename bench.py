@@ -168,11 +168,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # VO_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL (which refuses two ranks on one device) --
+    # runs the N > 1 code path end to end on a one-GPU box; its throughput means nothing
+    rehearsal = os.environ.get("VO_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
+    red_dev = "cpu" if rehearsal else "cuda"   # where the scalars of the cross-rank reductions live
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from visual_odometry_amd import capi
 
@@ -242,8 +251,8 @@ def main():
             r = step()
         barrier()
         dt = time.perf_counter() - t0
-        fps_ = shard.aggregate_fps(B * steps, dt, dist, "cuda")
-        dt = shard.max_over_ranks(dt, dist, "cuda")
+        fps_ = shard.aggregate_fps(B * steps, dt, dist, red_dev)
+        dt = shard.max_over_ranks(dt, dist, red_dev)
         # (context 0 alone, so that one launch's duration is not stretched by another context's kernels)
         ctx.batch_set_timing(True)
         acc_ = {}
