@@ -573,6 +573,13 @@ __device__ __forceinline__ int brief_round_bits(float v)
     return (int)(__float_as_uint(v + 12582912.f) & 0xffffffu);
 }
 constexpr int BS_PWD = (2 * BS_R + 1 + 3 + 3) / 4;
+constexpr int BS_KPG = 2;             // key points a 32-lane group handles one after the other
+constexpr int BS_KPB = 8 * BS_KPG;    // key points per block
+// The loads of both patches of a group are issued up front; while the group computes the first descriptor from
+// LDS the second patch is still in flight (it waits in registers and goes to LDS afterwards): the patch gathers,
+// not the arithmetic, bound this kernel.  A group is half a wave and only touches its own patch, so
+// nothing but program order is needed between its LDS writes and reads; the one block barrier is for the
+// pattern and the cos / sin table.
 __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8_t *__restrict__ pyr_blur,
                                                       const vo_kp *__restrict__ kps, int kp_stride,
                                                       const int *__restrict__ nkp,
@@ -581,69 +588,77 @@ __global__ __launch_bounds__(256) void k_brief_steered(OrbPlan plan, const uint8
 {
     __shared__ float4 s_pat[256];  // [test of a byte][byte]: x0 y0 x1 y1
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BS_R + 1) * BS_PWD];
-    __shared__ float s_cs[8][2];
+    __shared__ float s_cs[BS_KPB][2];
     const FrameBlock fb = frame_block(fg);
     s_pat[threadIdx.x] = reinterpret_cast<const float4 *>(pattern)[threadIdx.x];
     const int f = fb.frame;
-    const int g = threadIdx.x >> 5, k = fb.block * 8 + g;
+    const int g = threadIdx.x >> 5, k0 = fb.block * BS_KPB + g * BS_KPG;  // the group's first key point
     const int byte = threadIdx.x & 31;
     const int n_kp = nkp[f];
-    const bool live = k < n_kp;
-    // double-precision cos / sin of the block's eight angles: one lane each, in a single wave
-    if (threadIdx.x < 8 && fb.block * 8 + (int)threadIdx.x < n_kp) {
-        float angle = kps[(size_t)f * kp_stride + fb.block * 8 + threadIdx.x].angle;
+    // double-precision cos / sin of the block's angles: one lane each, in a single wave
+    if (threadIdx.x < BS_KPB && fb.block * BS_KPB + (int)threadIdx.x < n_kp) {
+        float angle = kps[(size_t)f * kp_stride + fb.block * BS_KPB + threadIdx.x].angle;
         angle *= (float)(3.14159265358979323846 / 180.f);
         s_cs[threadIdx.x][0] = (float)cos((double)angle);
         s_cs[threadIdx.x][1] = (float)sin((double)angle);
     }
-    int col0 = 0;
-    if (live) {
+    // block-uniform base + 32-bit offsets (a frame's pyramid is far below 4 GB).  The group's 32 lanes cover two
+    // rows of 16 dwords per step (11 of the 16 are patch columns, the others repeat the last one and are not
+    // stored): one add per load, and all loads are issued before the first LDS write
+    const uint8_t *frame = pyr_blur + (size_t)f * plan.frame_bytes;
+    constexpr int ROWS = 2 * BS_R + 1, PER = (ROWS + 1) / 2;
+    const int rh = byte >> 4, c = min(byte & 15, BS_PWD - 1);
+    const bool col_ok = (byte & 15) < BS_PWD;
+    uint32_t v[BS_KPG][PER];
+    // issue the patch loads of key point k (k < n_kp) into register set i; returns the patch column of its centre
+    auto issue = [&](int i, int k) -> int {
         const vo_kp kp = kps[(size_t)f * kp_stride + k];
         const OrbLevel L = plan.lv[kp.octave];
         const float inv = 1.f / L.scale;
         const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
         const int x_al = (cx - BS_R) & ~3;  // keypoints are >= 31 px inside their level: never negative
-        col0 = cx - x_al;
-        // block-uniform base + 32-bit offsets (a frame's pyramid is far below 4 GB).  The group's 32 lanes cover
-        // two rows of 16 dwords per step (11 of the 16 are patch columns, the others repeat the last one and are
-        // not stored): one add per load, and all loads are issued before the first LDS write
-        const uint8_t *frame = pyr_blur + (size_t)f * plan.frame_bytes;
-        constexpr int ROWS = 2 * BS_R + 1, PER = (ROWS + 1) / 2;
-        const int rh = byte >> 4, c = min(byte & 15, BS_PWD - 1);
-        const bool col_ok = (byte & 15) < BS_PWD;
         uint32_t off = (uint32_t)L.off + __umul24((uint32_t)(cy - BS_R + rh), (uint32_t)L.pitch) + (uint32_t)(x_al + 4 * c);
         const uint32_t step = 2u * (uint32_t)L.pitch;
-        uint32_t v[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
             // the last step has a single row: the upper half of the group re-reads it
             if (u == PER - 1 && (ROWS & 1)) off -= rh ? (uint32_t)L.pitch : 0u;
-            v[u] = *reinterpret_cast<const uint32_t *>(frame + off);
+            v[i][u] = *reinterpret_cast<const uint32_t *>(frame + off);
             off += step;
         }
+        return cx - x_al;
+    };
+    // the loads of all of the group's patches are issued up front, one register set per key point
+    int col0[BS_KPG];
+#pragma unroll
+    for (int i = 0; i < BS_KPG; i++) col0[i] = k0 + i < n_kp ? issue(i, k0 + i) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BS_KPG; i++) {
+        const int k = k0 + i;
+        if (k >= n_kp) break;  // uniform over the group (half a wave)
 #pragma unroll
         for (int u = 0; u < PER; u++)
-            if (col_ok && 2 * u + rh < ROWS) s_patch[g][(2 * u + rh) * BS_PWD + c] = v[u];
-    }
-    __syncthreads();
-    if (!live) return;
-    const float a = s_cs[g][0], b = s_cs[g][1];
-    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col0 -
-                            kBriefRoundBias * (BS_PWD * 4 + 1);
-    uint32_t val = 0;
+            if (col_ok && 2 * u + rh < ROWS) s_patch[g][(2 * u + rh) * BS_PWD + c] = v[i][u];
+        const int col_cur = col0[i];
+        const float a = s_cs[g * BS_KPG + i][0], b = s_cs[g * BS_KPG + i][1];
+        const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BS_R * (BS_PWD * 4) + col_cur -
+                                kBriefRoundBias * (BS_PWD * 4 + 1);
+        uint32_t val = 0;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const float4 p = s_pat[t * 32 + byte];
-        const float x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
-        // cvRound by adding 1.5 * 2^23: the sum's low mantissa bits hold the coordinate rounded to nearest even
-        // (|coordinate| < 2^22); the bias of the bit patterns is taken off the base address once
-        const int ix0 = brief_round_bits(x0 * a - y0 * b), iy0 = brief_round_bits(x0 * b + y0 * a);
-        const int ix1 = brief_round_bits(x1 * a - y1 * b), iy1 = brief_round_bits(x1 * b + y1 * a);
-        const int t0 = center[__mul24(iy0, BS_PWD * 4) + ix0];
-        const int t1 = center[__mul24(iy1, BS_PWD * 4) + ix1];
-        val |= (uint32_t)(t0 < t1) << t;
+        for (int t = 0; t < 8; t++) {
+            const float4 p = s_pat[t * 32 + byte];
+            const float x0 = p.x, y0 = p.y, x1 = p.z, y1 = p.w;
+            // cvRound by adding 1.5 * 2^23: the sum's low mantissa bits hold the coordinate rounded to nearest even
+            // (|coordinate| < 2^22); the bias of the bit patterns is taken off the base address once
+            const int ix0 = brief_round_bits(x0 * a - y0 * b), iy0 = brief_round_bits(x0 * b + y0 * a);
+            const int ix1 = brief_round_bits(x1 * a - y1 * b), iy1 = brief_round_bits(x1 * b + y1 * a);
+            const int t0 = center[__mul24(iy0, BS_PWD * 4) + ix0];
+            const int t1 = center[__mul24(iy1, BS_PWD * 4) + ix1];
+            val |= (uint32_t)(t0 < t1) << t;
+        }
+        desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
     }
-    desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
 }
 
 }  // namespace
@@ -769,7 +784,7 @@ void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const
 void launch_brief_steered(const OrbPlan &plan, int batch, const uint8_t *pyr_blur, const vo_kp *kps, int kp_stride,
                           const int *nkp, const float *pattern, uint8_t *desc, hipStream_t s)
 {
-    const int per_frame = (kp_stride + 7) / 8;
+    const int per_frame = (kp_stride + BS_KPB - 1) / BS_KPB;
     hipLaunchKernelGGL(k_brief_steered, dim3((unsigned)(per_frame * batch)), dim3(256), 0, s, plan, pyr_blur, kps,
                        kp_stride, nkp, pattern, desc, frame_grid(per_frame, batch));
 }
