@@ -1199,6 +1199,11 @@ void launch_select(const uint32_t *cand, const uint32_t *tile_count, uint32_t *f
 // global ones.
 constexpr int BR_R = 13;
 constexpr int BR_PWD = (2 * BR_R + 1 + 3 + 3) / 4;  // dwords per staged row (any alignment of the first column)
+constexpr int BR_KPG = 2;           // key points a 32-lane group handles one after the other
+constexpr int BR_KPB = 8 * BR_KPG;  // key points per block
+// (The loads of both patches of a group are issued up front; the second patch waits in registers while the first
+// descriptor is computed from LDS.  A group is half a wave and only touches its own patch, so program order is all
+// that is needed between its LDS writes and reads; the block barrier is for the pattern.)
 __global__ __launch_bounds__(256) void k_brief(PlaneBatch blur, const vo_kp *__restrict__ kps, int kp_stride,
                                                const int *__restrict__ nkp,
                                                const int8_t *__restrict__ pattern,
@@ -1208,47 +1213,55 @@ __global__ __launch_bounds__(256) void k_brief(PlaneBatch blur, const vo_kp *__r
     __shared__ __attribute__((aligned(16))) uint32_t s_patch[8][(2 * BR_R + 1) * BR_PWD];
     reinterpret_cast<uint32_t *>(s_pat)[threadIdx.x] = reinterpret_cast<const uint32_t *>(pattern)[threadIdx.x];
     const int f = blockIdx.y;
-    const int g = threadIdx.x >> 5, k = blockIdx.x * 8 + g;
+    const int g = threadIdx.x >> 5, k0 = blockIdx.x * BR_KPB + g * BR_KPG;  // the group's first key point
     const int byte = threadIdx.x & 31;
-    const bool live = k < nkp[f];
-    int col0 = 0;
-    if (live) {
-        const vo_kp kp = kps[(size_t)f * kp_stride + k];
-        const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
-        const int x_al = (cx - BR_R) & ~3;  // keypoints are >= 31 px inside the image: never negative
-        col0 = cx - x_al;
-        const uint8_t *src = blur.base + f * blur.plane_stride + (size_t)(cy - BR_R) * blur.pitch + x_al;
-        // all of a lane's loads are issued before the first LDS write (lanes past the end re-read the last dword)
-        constexpr int N = (2 * BR_R + 1) * BR_PWD, PER = (N + 31) / 32;
-        uint32_t v[PER];
+    const int n_kp = nkp[f];
+    // all of a lane's loads are issued before the first LDS write (lanes past the end re-read the last dword)
+    constexpr int N = (2 * BR_R + 1) * BR_PWD, PER = (N + 31) / 32;
+    uint32_t v[BR_KPG][PER];
+    int col0[BR_KPG];
 #pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int i = min(byte + 32 * u, N - 1);
-            const int r = i / BR_PWD, c = i - r * BR_PWD;
-            v[u] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * blur.pitch + 4 * c);
+    for (int i = 0; i < BR_KPG; i++) {
+        col0[i] = 0;
+        if (k0 + i < n_kp) {
+            const vo_kp kp = kps[(size_t)f * kp_stride + k0 + i];
+            const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+            const int x_al = (cx - BR_R) & ~3;  // keypoints are >= 31 px inside the image: never negative
+            col0[i] = cx - x_al;
+            const uint8_t *src = blur.base + f * blur.plane_stride + (size_t)(cy - BR_R) * blur.pitch + x_al;
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int j = min(byte + 32 * u, N - 1);
+                const int r = j / BR_PWD, c = j - r * BR_PWD;
+                v[i][u] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * blur.pitch + 4 * c);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < PER; u++)
-            if (byte + 32 * u < N) s_patch[g][byte + 32 * u] = v[u];
     }
     __syncthreads();
-    if (!live) return;
-    const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BR_R * (BR_PWD * 4) + col0;
-    const int8_t *p = s_pat + byte * 32;
-    uint32_t val = 0;
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-        const int t0 = center[p[4 * b + 1] * (BR_PWD * 4) + p[4 * b + 0]];
-        const int t1 = center[p[4 * b + 3] * (BR_PWD * 4) + p[4 * b + 2]];
-        val |= (uint32_t)(t0 < t1) << b;
+    for (int i = 0; i < BR_KPG; i++) {
+        const int k = k0 + i;
+        if (k >= n_kp) break;  // uniform over the group (half a wave)
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (byte + 32 * u < N) s_patch[g][byte + 32 * u] = v[i][u];
+        const uint8_t *center = reinterpret_cast<const uint8_t *>(s_patch[g]) + BR_R * (BR_PWD * 4) + col0[i];
+        const int8_t *p = s_pat + byte * 32;
+        uint32_t val = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const int t0 = center[p[4 * b + 1] * (BR_PWD * 4) + p[4 * b + 0]];
+            const int t1 = center[p[4 * b + 3] * (BR_PWD * 4) + p[4 * b + 2]];
+            val |= (uint32_t)(t0 < t1) << b;
+        }
+        desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
     }
-    desc[((size_t)f * kp_stride + k) * 32 + byte] = (uint8_t)val;
 }
 
 void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride, const int *nkp, const int8_t *pattern,
                   uint8_t *desc, int batch, hipStream_t s)
 {
-    dim3 grid((kp_stride + 7) / 8, batch);
+    dim3 grid((kp_stride + BR_KPB - 1) / BR_KPB, batch);
     hipLaunchKernelGGL(k_brief, grid, dim3(256), 0, s, blur, kps, kp_stride, nkp, pattern, desc);
 }
 
