@@ -405,11 +405,11 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
 #pragma unroll
             for (int i = 0; i < 12; i++) pv[i] = __shfl(v[i], src);
             const bool am_p = gl < y;
-            double so = 0, sp = 0, gamma = 0;
+            double so = 0, gamma = 0;
 #pragma unroll
             for (int i = 0; i < ROWS; i++) so += g[i] * g[i];
-#pragma unroll
-            for (int i = 0; i < ROWS; i++) sp += pg[i] * pg[i];
+            // (the partner lane has just summed its own column the same way)
+            const double sp = __shfl(so, src);
 #pragma unroll
             for (int i = 0; i < ROWS; i++) gamma += g[i] * pg[i];
             const double alpha = am_p ? so : sp, beta = am_p ? sp : so;
@@ -419,17 +419,13 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
                 const double zeta = (beta - alpha) / (2 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
                 const double c = 1 / sqrt(1 + t * t), sn = c * t;
-                if (am_p) {
+                // the lower column of the pair becomes c p - s q, the upper one s p + c q: one expression for both
+                // (a - b and a + (-b) round alike, and so do a + b and b + a)
+                const double s2 = am_p ? -sn : sn;
 #pragma unroll
-                    for (int i = 0; i < ROWS; i++) g[i] = c * g[i] - sn * pg[i];
+                for (int i = 0; i < ROWS; i++) g[i] = c * g[i] + s2 * pg[i];
 #pragma unroll
-                    for (int i = 0; i < 12; i++) v[i] = c * v[i] - sn * pv[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < ROWS; i++) g[i] = sn * pg[i] + c * g[i];
-#pragma unroll
-                    for (int i = 0; i < 12; i++) v[i] = sn * pv[i] + c * v[i];
-                }
+                for (int i = 0; i < 12; i++) v[i] = c * v[i] + s2 * pv[i];
             }
         }
         if (!__any(rotated)) break;
