@@ -200,8 +200,8 @@ int vo_detect_orb(vo_ctx *ctx, const uint8_t *gray, int w, int h, int stride,
  * 7x7-Gaussian version the descriptors were sampled from.  Of the blurred
  * levels above level 0 only the pixels a descriptor can sample are defined
  * (key points lie 31 px inside a level, the rotated pattern reaches 18 px): the
- * outermost 13 rows at the top and the bottom and the outermost 13 columns on
- * the right may hold stale data.  dst may be null to query the level size only. */
+ * outermost 13 columns and rows on the right and at the bottom may hold stale
+ * data.  dst may be null to query the level size only. */
 int vo_orb_get_level(vo_ctx *ctx, int frame, int level, int blurred, uint8_t *dst,
                      int dst_stride, int *w_out, int *h_out);
 

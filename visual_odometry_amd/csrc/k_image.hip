@@ -152,7 +152,7 @@ __device__ __forceinline__ bool fast_quick(uint32_t v, uint32_t p0, uint32_t p8,
     do {                                                                                                   \
         if (VO_FE_CUT == (n)) {                                                                            \
             if (cand && threadIdx.x == 0)                                                                  \
-                tile_count[(size_t)tile.frame * tiles_x * tiles_y + ty * tiles_x + tile.x0 / FE_TW] = 0; \
+                tile_count[(size_t)tile.frame * tiles_x * tiles_y + (tile.y0 / FE_TH) * tiles_x + tile.x0 / FE_TW] = 0; \
             return;                                                                                        \
         }                                                                                                  \
     } while (0)
@@ -600,8 +600,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     {
         tile.frame = (int)magic_div((uint32_t)col, inv_tiles_x);  // col / tiles_x
         tile.x0 = (col - tile.frame * tiles_x) * FE_TW;
-        // (with an unused edge the tile rows start below it: the rows above hold nothing a later stage reads either)
-        tile.y0 = ty * FE_TH + (unused_edge > 0 && unused_edge <= margin ? unused_edge : 0);
+        tile.y0 = ty * FE_TH;
         tile.inside = tile.x0 >= 4 && tile.x0 + FE_PITCH - 4 <= width && tile.y0 >= 4 &&
                       tile.y0 + FE_GROWS - 4 <= height;
         tile.fast = !tile.inside && aligned && width >= 8 && height >= 8;
@@ -614,7 +613,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     // (no corners are looked for there: unused_edge <= margin; the caller reads the blurred plane only further
     // inside): it only reports an empty corner list.
     if (unused_edge > 0 && unused_edge <= margin && (x0 >= width - unused_edge || y0 >= height - unused_edge)) {
-        if (cand && tid == 0) tile_count[(size_t)f * tiles_x * tiles_y + ty * tiles_x + x0 / FE_TW] = 0;
+        if (cand && tid == 0) tile_count[(size_t)f * tiles_x * tiles_y + (y0 / FE_TH) * tiles_x + x0 / FE_TW] = 0;
         return;
     }
 
@@ -787,7 +786,7 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
 
     // ---- 3. non-max suppression of the queued corners (score row sr <-> tile row sr + 3), direct emission
     if (cand) {
-        const int tile_id = ty * tiles_x + x0 / FE_TW;
+        const int tile_id = (y0 / FE_TH) * tiles_x + x0 / FE_TW;
         uint32_t *out = cand + ((size_t)f * tiles_x * tiles_y + tile_id) * kTileCap;
         for (int e0 = wave * 64; e0 < qn; e0 += FE_THREADS) {
             const int e = e0 + lane;
@@ -921,8 +920,7 @@ struct FeLevels {
     } lv[kOrbMaxLevels];
     int total_groups;
     int by_rows;          // groups enumerate (tile-row group, tile column) instead of (tile-column group, tile row)
-    int unused_edge;      // tile rows start this far below the top edge; tiles that start this close to the right /
-                          // bottom edge are skipped (see fe_tile)
+    int unused_edge;      // tiles that start this close to the right / bottom edge are skipped (see fe_tile)
     size_t frame_stride;  // bytes between the planes of consecutive frames (same for input and output)
 };
 
