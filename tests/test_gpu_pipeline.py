@@ -346,3 +346,52 @@ def test_batch_is_reproducible_run_to_run(ctx, levels):
     assert runs[0][0] == runs[1][0]
     assert runs[0][1] == runs[1][1]
     assert res["pnp_success"].reshape(S, F)[:, 1:].all()
+
+
+@pytest.mark.parametrize("levels", [0, 8])
+def test_batch_with_degenerate_streams(oracle, levels):
+    """One launch whose streams run into every empty case of the chain side by side with an ordinary stream: blank
+    frames (no key points at all), a blank frame between textured ones (nothing to match against, then nothing to
+    match), depth that is zero / NaN / out of range everywhere (matches but no 3-D points, no pose), and a stream
+    whose second frame shows something else entirely (a handful of matches at most)."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    F = 3
+    a = synth.make_sequence(cam, F, seed=6100, channels=4)
+    b = synth.make_sequence(cam, F, seed=6200, channels=4)
+    blank = np.full_like(a["frames"][0], 90)
+    bad_depth = a["depth"].copy()
+    bad_depth[0][:] = 0.0
+    bad_depth[1][:] = np.nan
+    bad_depth[2][:] = 30000.0
+    streams = [
+        (a["frames"], a["depth"]),                                                  # ordinary
+        (np.stack([blank] * F), a["depth"]),                                         # never a key point
+        (np.stack([a["frames"][0], blank, a["frames"][2]]), a["depth"]),             # a blank frame in the middle
+        (a["frames"], bad_depth),                                                    # no usable depth
+        (np.stack([a["frames"][0], b["frames"][1], a["frames"][2]]), a["depth"]),    # unrelated middle frame
+    ]
+    S = len(streams)
+    from visual_odometry_amd import capi
+    ctx = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=864, max_batch=S * F)
+    try:
+        refs = [OracleStream(K, 800, 20, orb_levels=levels, feature_cap=ctx.max_features) for _ in range(S)]
+        ctx.batch_configure(cam.width, cam.height, 4, n_streams=S, frames_per_stream=F, max_features=800,
+                            fast_threshold=20, camera=K, orb_levels=levels)
+        frames = np.stack([streams[s][0][f] for s in range(S) for f in range(F)])
+        depth = np.stack([streams[s][1][f] for s in range(S) for f in range(F)])
+        ctx.batch_submit(frames, depth)
+        res = ctx.batch_wait()
+        for s in range(S):
+            for f in range(F):
+                ref = refs[s].process(streams[s][0][f], streams[s][1][f])
+                _compare_frame(ctx, res, s * F + f, ref, pose=True)
+    finally:
+        ctx.close()
+    r = res.reshape(S, F)
+    assert r["pnp_success"][0, 1:].all()
+    assert (r["n_keypoints"][1] == 0).all() and (r["n_matches"][1] == 0).all() and not r["pnp_success"][1].any()
+    assert r["n_keypoints"][2, 1] == 0 and r["n_matches"][2, 1] == 0 and r["n_matches"][2, 2] == 0
+    assert (r["n_matches"][3, 1:] > 50).all() and not r["pnp_success"][3].any()
+    assert r["n_matches"][4, 1] < 30
