@@ -28,8 +28,10 @@ namespace vo {
 
 constexpr int PR_THREADS = 128;
 constexpr int PR_WAVES = PR_THREADS / kWave;
-constexpr int PR_GROUP = 16;                      // lanes per hypothesis
-constexpr int PR_CHUNK = PR_THREADS / PR_GROUP;   // hypotheses per round
+constexpr int PR_GROUP = 12;                      // lanes per hypothesis: one per column of EPnP's 10 x 12 matrix
+constexpr int PR_PER_WAVE = kWave / PR_GROUP;     // hypotheses per wave (the last four lanes of a wave stay idle)
+constexpr int PR_CHUNK = PR_WAVES * PR_PER_WAVE;  // hypotheses per round
+constexpr int PR_FIRST = 8;                       // hypotheses of the first round
 constexpr int PR_WIN = PR_CHUNK * 5 + 96;         // RNG words examined per round
 constexpr int PR_NRED = 45;                       // 36 JtJ + 6 JtErr + |err|^2 (pose); 36 + 8 + 1 (homography)
 
@@ -362,7 +364,7 @@ __device__ void rodrigues_m2v(const double *R, double *r)
 }
 
 // ---------------------------------------------------------------------
-// one-sided Jacobi over a 16-lane group
+// one-sided Jacobi over a group of PR_GROUP lanes
 // ---------------------------------------------------------------------
 
 // partner of column x in round r of the 12-player round-robin tournament
@@ -374,8 +376,8 @@ __device__ __forceinline__ int rr_partner(int x, int r)
     return y < 0 ? y + 11 : y;
 }
 
-// Right singular vectors of a ROWS x 12 matrix whose column gl (< 12) lives in
-// g[] of lane gl of each 16-lane group.  On return v[] is the group's column
+// Right singular vectors of a ROWS x 12 matrix whose column gl lives in
+// g[] of lane gl of each PR_GROUP-lane group (lanes past the last whole group idle).  On return v[] is the group's column
 // gl of V and *norm2 the squared norm of the rotated column gl (a squared
 // singular value); *rank is that value's position in descending order (ties
 // by column index).  Every lane of the wave must call this.
@@ -383,8 +385,8 @@ template <int ROWS>
 __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *norm2, int *rank)
 {
     const int lane = threadIdx.x & 63;
-    const int base = lane & ~(PR_GROUP - 1);
-    const bool col = gl < 12;
+    const int grp = lane / PR_GROUP, base = grp * PR_GROUP;
+    const bool col = gl < 12 && grp < PR_PER_WAVE;
 #pragma unroll
     for (int i = 0; i < 12; i++) v[i] = (i == gl) ? 1.0 : 0.0;
     double own = 0;
@@ -677,7 +679,7 @@ struct PrShared {
     uint16_t r[PR_WIN];
     uint8_t cons[PR_WIN];
     int wave_tot[PR_WAVES];
-    int nchunk, iter, niters, max_good, done;
+    int nchunk, per_wave, iter, niters, max_good, done;
     long long pos;
     int scan_base;
     int lm_ok;
@@ -1320,11 +1322,15 @@ extern "C" int vo_debug_pnp_stamps(unsigned long long *out)
 #define PNP_STAMP(i) do { } while (0)
 #endif
 
-// solve hypothesis `h` of the round (one per 16-lane group); all lanes call
-__device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img, int h, bool active, double fx,
-                                 double fy, double cx, double cy)
+// solve hypotheses first_h .. first_h + per_wave - 1 of the round (those below nc), one per group of PR_GROUP
+// lanes; all lanes of the wave call
+__device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img, int first_h, int per_wave, int nc,
+                                 double fx, double fy, double cx, double cy)
 {
-    const int gl = threadIdx.x & (PR_GROUP - 1);
+    const int lane = threadIdx.x & 63, grp = lane / PR_GROUP, gl = lane - grp * PR_GROUP;
+    const bool member = grp < per_wave;  // the other lanes of the wave follow along idle
+    const int h = member ? first_h + grp : first_h;
+    const bool active = member && h < nc;
     Epnp5 e;
     e.fu = fx; e.fv = fy; e.uc = cx; e.vc = cy;
     int idx[5] = {0, 1, 2, 3, 4};
@@ -1350,7 +1356,7 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
             g[2 * i] = c == 0 ? a * e.fu : (c == 2 ? a * (e.uc - e.us[2 * i]) : 0.0);
             g[2 * i + 1] = c == 1 ? a * e.fv : (c == 2 ? a * (e.vc - e.us[2 * i + 1]) : 0.0);
         }
-        if (gl >= 12 || !ok) {
+        if (!active || !ok) {  // (a zero matrix: the decomposition has nothing to rotate)
 #pragma unroll
             for (int i = 0; i < 10; i++) g[i] = 0;
         }
@@ -1360,7 +1366,7 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     group_svd12<10>(g, v, gl, &n2, &rank);
     PNP_STAMP(13);
     // ranks 11, 10, 9, 8 are the four smallest singular values: vv[0..3]
-    if (gl < 12 && rank >= 8) {
+    if (active && rank >= 8) {
 #pragma unroll
         for (int i = 0; i < 12; i++) S.vv[h][11 - rank][i] = v[i];
     }
@@ -1382,7 +1388,7 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     }
     PNP_STAMP(14);
     // epnp::compute_pose keeps approximation 1 unless 2 reprojects better, then 3 unless it beats that
-    const int base = (threadIdx.x & 63) & ~(PR_GROUP - 1);
+    const int base = grp * PR_GROUP;
     const double rep1 = __shfl(rep, base), rep2 = __shfl(rep, base + 1), rep3 = __shfl(rep, base + 2);
     int win = 0;
     double best_rep = rep1;
@@ -1392,7 +1398,7 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     for (int i = 0; i < 9; i++) R[i] = __shfl(R[i], base + win);
 #pragma unroll
     for (int i = 0; i < 3; i++) t[i] = __shfl(t[i], base + win);
-    if (gl == 0) {
+    if (gl == 0 && active) {
         bool good = run;
 #pragma unroll
         for (int i = 0; i < 9; i++) good = good && isfinite(R[i]);
@@ -1473,9 +1479,9 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     if (n == 5) {
         // OpenCV runs the minimal solver once and reports every point as inlier
         if (tid < 5) S.r[tid] = (uint16_t)tid;
-        if (tid < kWave / PR_GROUP) S.start[tid] = 0;
+        if (tid == 0) S.start[0] = 0;
         __syncthreads();
-        if (wave == 0) solve_hypothesis(S, obj, img, tid / PR_GROUP, tid < PR_GROUP, fx, fy, cx, cy);
+        if (wave == 0) solve_hypothesis(S, obj, img, 0, 1, 1, fx, fy, cx, cy);
         __syncthreads();
         if (tid == 0) {
             const int ok = S.ok[0];
@@ -1506,7 +1512,10 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         __syncthreads();
         if (tid == 0) {
             int w = 0, nc = 0;
-            const int want = min(PR_CHUNK, S.niters - S.iter);
+            // the first round is the only one of most frames: four hypotheses per wave (a wave's decomposition
+            // takes as many sweeps as its slowest group needs); later rounds fill all five groups of a wave
+            S.per_wave = S.iter == 0 ? PR_FIRST / PR_WAVES : PR_PER_WAVE;
+            const int want = min(S.per_wave * PR_WAVES, S.niters - S.iter);
             while (nc < want && w < PR_WIN && S.cons[w] != 0) { S.start[nc++] = w; w += S.cons[w]; }
             S.nchunk = nc;
             S.pos = pos + w;
@@ -1515,11 +1524,9 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
         __syncthreads();
         PNP_STAMP(2);
         const int nc = S.nchunk;
-        {
-            const int h = tid / PR_GROUP;
-            // a wave takes part when any of its four hypotheses exists
-            if ((wave * (kWave / PR_GROUP)) < nc) solve_hypothesis(S, obj, img, h, h < nc, fx, fy, cx, cy);
-        }
+        // a wave takes part when any of its hypotheses exists
+        const int pw = S.per_wave;
+        if (wave * pw < nc) solve_hypothesis(S, obj, img, wave * pw, pw, nc, fx, fy, cx, cy);
         __syncthreads();
         PNP_STAMP(3);
         for (int h = wave; h < nc; h += PR_WAVES) {
