@@ -118,7 +118,8 @@ def cpu_baseline_all_cores(workers, frames, n_frames, max_features, orb_levels):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps (the default keeps the timed region above half a second)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=32, help="independent camera streams per GPU")
     ap.add_argument("--frames", type=int, default=16, help="consecutive frames per stream per step (even)")
@@ -136,10 +137,12 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=16,
                     help="host cores for the all-core CPU baseline (one stream each; 0 = skip; capped at the CPU count)")
     ap.add_argument("--render-workers", type=int, default=16, help="processes rendering the synthetic streams")
-    ap.add_argument("--hard-scene", type=int, default=1,
-                    help="also run the same launch on streams with independently moving objects (0 = skip)")
-    ap.add_argument("--flat-scene", type=int, default=1,
-                    help="also run the same launch on streams that look at a flat wall (0 = skip)")
+    ap.add_argument("--hard-scene", type=int, default=None,
+                    help="also run the same launch on streams with independently moving objects (0 = skip; "
+                         "default: on with one GPU, off with several)")
+    ap.add_argument("--flat-scene", type=int, default=None,
+                    help="also run the same launch on streams that look at a flat wall (0 = skip; default: on with "
+                         "one GPU, off with several)")
     ap.add_argument("--config", choices=("hd720", "kitti8"), default="hd720",
                     help="hd720: the headline workload, the same number of streams on every GPU (weak scaling); "
                          "kitti8: eight KITTI-shaped 1241x376 BGR streams in total, dealt round-robin to the ranks "
@@ -151,6 +154,18 @@ def main():
                     help="also time the CPU baseline of the other detector (the one-level FAST sequence the "
                          "reference node runs) for the record (0 = skip)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process touches no GPU; it starts the N ranks as fresh child
+        # processes of this same script, relays rank 0's one line and passes on a failing rank's status
+        from visual_odometry_amd import shard
+        sys.exit(shard.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.hard_scene is None:
+        args.hard_scene = 0 if multi else 1
+    if args.flat_scene is None:
+        args.flat_scene = 0 if multi else 1
 
     # the all-core CPU baseline runs first, in child processes started before this process initialises the GPU
     cpu_all = None
@@ -166,8 +181,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (which "
+                         "starts the ranks itself) or under torch.distributed.run --nproc-per-node N")
     # VO_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL (which refuses two ranks on one device) --
     # runs the N > 1 code path end to end on a one-GPU box; its throughput means nothing
     rehearsal = os.environ.get("VO_BENCH_REHEARSAL", "0") == "1"
@@ -189,7 +204,8 @@ def main():
     kitti = args.config == "kitti8"
     NC = max(1, args.contexts) if not kitti else 1
     assert args.streams % NC == 0, "--streams must be a multiple of --contexts"
-    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1))
+    # the ranks of one node share its host cores: each renders with its share of the workers
+    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1) // world)
     if kitti:
         # configs[3]: eight streams in all; rank r owns streams r, r + world, ... and renders exactly those (a stream's
         # seed does not depend on the number of ranks)
@@ -431,7 +447,8 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32 (image), %s (match), f32 (Harris, angle), f64 (RANSAC)" %
                      ("int8 MFMA -> int32" if args.matcher == "mfma" else "u32 xor/popcount"),
             "data": "synthetic",
-            "config": {"workload": ("kitti_1241x376_bgr_8_streams_total_2000kp_%s_ratio_Fransac_pnp" if kitti else
+            "config": {"inputs": "hbm_resident",
+                       "workload": ("kitti_1241x376_bgr_8_streams_total_2000kp_%s_ratio_Fransac_pnp" if kitti else
                                     "hd720_bgra_mono_stream_2000kp_%s_ratio_Fransac_pnp") %
                                    ("orb8level" if levels else "fast1level"),
                        "detector": args.detector, "matcher": args.matcher, "pyramid_levels": levels or 1,
