@@ -147,7 +147,13 @@ int vo_knn2_hamming(vo_ctx *ctx, const uint8_t *query, int n_query,
  * n_query and n_train may not exceed VO_KNN2_STATIC_MAX (VO_ERR_ARG otherwise;
  * vo_static_last_error() holds the message).  All calls on one GPU share that
  * GPU's array: calls that overlap on one GPU (two threads, two streams) race;
- * serialise them. */
+ * serialise them.
+ * To record a call into a HIP graph (hipStreamBeginCapture on hip_stream) three
+ * conditions hold, because stream capture accepts neither module loading, nor
+ * synchronisation, nor copies from pageable host memory: (1) one call on that
+ * device has been made before the capture starts -- n_query = 0 is enough, it
+ * only looks up the array's address; (2) query, train and out are device
+ * memory or pinned host memory; (3) wait == 0. */
 #define VO_KNN2_STATIC_MAX 4096
 int vo_knn2_hamming_static(int device, void *hip_stream, const uint8_t *query, int n_query,
                            const uint8_t *train, int n_train, vo_knn2 *out, int wait);
@@ -448,8 +454,9 @@ int vo_batch_get_packed(vo_ctx *ctx, int frame, vo_frame_view *view);
  * it shortens the launch-bound single-frame path).  The graph is captured on
  * the first submit after enabling and again whenever the configuration, the
  * camera or the device input pointers change; host inputs go through the
- * context's staging area and never force a re-capture.  Per-stage event
- * timing (vo_batch_set_timing) is ignored while a graph is in use. */
+ * context's staging area and never force a re-capture.  A graph replay records
+ * no per-stage events: vo_batch_get_timing() returns VO_ERR_STATE after a batch
+ * that ran as a graph. */
 int vo_batch_set_graph(vo_ctx *ctx, int enable);
 
 /* Pinned host memory for frames and depth planes: vo_batch_submit copies from

@@ -124,3 +124,79 @@ def test_packed_output_is_refused_for_large_batches():
         assert (res["n_keypoints"] == res["n_keypoints"][0]).all() and res["n_keypoints"][0] > 100
     finally:
         c.close()
+
+
+def test_graph_is_dropped_when_a_single_frame_call_replans_the_pyramid(ctx):
+    """A recorded batch chain holds the pyramid's buffer addresses and level tables.  A single-frame full-detector
+    call at a larger geometry re-plans (and reallocates) them; the next graph batch must record the chain again
+    instead of replaying the stale one.  Every segment equals the plain path."""
+    cam = synth.CONFIG_CAMERAS["vga"]
+    seqs = [synth.make_sequence(cam, 6, seed=4700, channels=4)]
+    plain = _run(ctx, cam, seqs, 1, 6, 4, packed=False, graph=False)
+    big = synth.make_sequence(synth.CONFIG_CAMERAS["hd1080"], 1, seed=4701, channels=1)["frames"][0]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=1, max_features=600,
+                        fast_threshold=20, camera=K, orb_levels=4)
+    ctx.batch_set_packed_output(True)
+    ctx.batch_set_graph(True)
+    got = []
+    for i in range(6):
+        if i in (2, 4):
+            # between two graph batches: the context's largest frame through the single-frame operator
+            kps, _ = ctx.detect_orb(big, nfeatures=3000, nlevels=8)
+            assert len(kps) > 1000
+        ctx.batch_submit(seqs[0]["frames"][i][None], seqs[0]["depth"][i][None])
+        res = ctx.batch_wait()
+        p = ctx.batch_packed(0)
+        rec = {k: p[k] for k in ("kps", "desc", "matches", "tracked", "valid", "pts3", "inliers")}
+        rec["result"] = res[0].copy()
+        got.append(rec)
+    ctx.batch_set_graph(False)
+    ctx.batch_set_packed_output(False)
+    _same(got, plain)
+
+
+def test_stage_timing_is_refused_after_a_graph_replay(ctx):
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    seq = synth.make_sequence(cam, 2, seed=4800, channels=4)
+    ctx.batch_configure(cam.width, cam.height, 4, max_features=600, camera=(cam.fx, cam.fy, cam.cx, cam.cy))
+    ctx.batch_set_timing(True)
+    try:
+        ctx.batch_set_graph(True)
+        ctx.batch_submit(seq["frames"][:1], seq["depth"][:1])
+        ctx.batch_wait()
+        with pytest.raises(capi.VoError) as e:
+            ctx.batch_timing()
+        assert e.value.code == capi.VO_ERR_STATE
+        ctx.batch_set_graph(False)
+        ctx.batch_submit(seq["frames"][1:], seq["depth"][1:])
+        ctx.batch_wait()
+        t = ctx.batch_timing()
+        assert len(t) == 12 and all(v >= 0 for v in t.values()) and sum(t.values()) > 0
+    finally:
+        ctx.batch_set_timing(False)
+        ctx.batch_set_graph(False)
+
+
+def test_failed_reconfigure_with_packed_output_leaves_the_context_as_it_was():
+    """vo_batch_configure for a batch whose packed block would exceed 32 MiB fails before anything is committed: the
+    old configuration keeps working."""
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    c = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=2064, max_batch=128)
+    try:
+        K = (cam.fx, cam.fy, cam.cx, cam.cy)
+        c.batch_configure(cam.width, cam.height, 1, n_streams=2, frames_per_stream=1, max_features=500, camera=K)
+        c.batch_set_packed_output(True)
+        seq = synth.make_sequence(cam, 2, seed=10, channels=1)
+        c.batch_submit(np.stack([seq["frames"][0]] * 2), np.stack([seq["depth"][0]] * 2))
+        first = c.batch_wait().copy()
+        with pytest.raises(capi.VoError):
+            c.batch_configure(cam.width, cam.height, 1, n_streams=128, frames_per_stream=1, max_features=500, camera=K)
+        c.batch_submit(np.stack([seq["frames"][1]] * 2), np.stack([seq["depth"][1]] * 2))
+        res = c.batch_wait()
+        assert len(res) == 2 and (res["n_matches"] > 50).all() and (res["pnp_success"] == 1).all()
+        assert (first["n_keypoints"] > 100).all()
+    finally:
+        c.close()

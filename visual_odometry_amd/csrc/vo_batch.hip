@@ -230,15 +230,16 @@ int vo_batch_configure(vo_ctx *c, const vo_batch_cfg *b)
                                      b->orb_levels, b->max_features, b->n_streams * b->frames_per_stream);
         if (rc) return rc;
     }
+    if (c->packed) {
+        // before anything is committed: a batch too large for the packed output leaves the context as it was
+        const int rc = ensure_pack(c, b->n_streams * b->frames_per_stream);
+        if (rc) return rc;
+    }
     c->bcfg = *b;
     c->configured = true;
     c->submitted = false;
     c->drop_graph();
     c->packed_valid = false;
-    if (c->packed) {
-        const int rc = ensure_pack(c, b->n_streams * b->frames_per_stream);
-        if (rc) return rc;
-    }
     // the NaN fill of the stereo depth planes covers the geometry and batch of the configuration it was made under
     c->depth_planes_nan = false;
     return vo_batch_reset(c);
@@ -480,15 +481,21 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     };
 
     if (c->use_graph) {
-        vo_ctx::GraphKey key{};
+        // (whether the streams' first frames are linked to their carry slots is device data -- d_qslot,
+        // d_has_prev -- and needs no new recording)
+        if (c->graph_exec && c->graph_key.generation != c->generation) c->drop_graph();
+        vo_ctx::GraphKey key;
         key.frames = src; key.depth = dsrc; key.right = rsrc;
         key.row_stride = row_stride; key.depth_row_stride = depth_row_stride;
         key.frame_stride = frame_stride; key.depth_frame_stride = depth_frame_stride;
-        key.cfg = b;
-        if (st) key.st = *st;
-        key.packed = c->packed; key.popcount = c->matcher_popcount; key.linked = c->first_pairs_linked;
-        if (!c->graph_exec || memcmp(&key, &c->graph_key, sizeof(key)) != 0) {
-            c->drop_graph();
+        if (st) {
+            key.st_baseline = st->baseline; key.st_band = st->band; key.st_min_disparity = st->min_disparity;
+            key.st_max_disparity = st->max_disparity; key.st_ratio = st->ratio;
+        }
+        key.packed = c->packed; key.popcount = c->matcher_popcount;
+        if (c->graph_exec && !(key == c->graph_key)) c->drop_graph();
+        key.generation = c->generation;
+        if (!c->graph_exec) {
             hipGraph_t graph = nullptr;
             HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
             c->capturing = true;
@@ -516,6 +523,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     c->submitted = true;
     c->streams_started = true;
     c->last_batch_stereo = right != nullptr;
+    c->last_submit_graph = c->use_graph;
     c->packed_valid = c->packed;
     return VO_OK;
 }
@@ -562,6 +570,7 @@ int vo_batch_set_camera(vo_ctx *c, double fx, double fy, double cx, double cy)
     if (!(fx > 0 && fy > 0)) return bfail(c, VO_ERR_ARG, "vo_batch_set_camera: fx, fy must be positive");
     c->bcfg.fx = fx; c->bcfg.fy = fy; c->bcfg.cx = cx; c->bcfg.cy = cy;
     c->bcfg.enable_pose = 1;
+    c->generation++;  // the intrinsics are kernel arguments of a recorded chain
     return VO_OK;
 }
 
@@ -699,6 +708,9 @@ int vo_batch_get_timing(vo_ctx *c, float *ms)
     if (!c) return VO_ERR_ARG;
     if (!c->timing || c->submitted || !ms)
         return bfail(c, VO_ERR_STATE, "vo_batch_get_timing: enable timing, submit and wait first");
+    if (c->last_submit_graph)
+        return bfail(c, VO_ERR_STATE, "vo_batch_get_timing: the last batch was a graph replay, which records no "
+                                      "per-stage events (vo_batch_set_graph(ctx, 0) for stage timing)");
     HIP_TRY(c, hipSetDevice(c->device));
     for (int i = 0; i < vo_ctx::kStages; i++) HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
     return VO_OK;

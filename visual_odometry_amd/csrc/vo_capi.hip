@@ -675,6 +675,8 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
                     "(1 < scale <= 2, 1..8 levels, smallest level >= 7 px, <= 1792 features per level)",
                     w, h, (double)scale_factor, nlevels, nfeatures);
     HIP_TRY(ctx, hipStreamSynchronize(stream));
+    // a recorded batch chain holds the old plan's level tables and buffer addresses
+    drop_graph();
     const size_t pyr_need = p.frame_bytes * batch;
     if (pyr_need > orb_pyr_cap) {
         if (d_pyr) (void)hipFree(d_pyr);

@@ -104,19 +104,36 @@ struct vo_ctx {
     double wall_clock_khz = 0;
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;
-    // what the captured graph was built for
+    // what the captured graph was built for.  `generation` counts every event that invalidates a recorded chain
+    // without showing in the other fields: a new batch configuration or camera, a re-planned pyramid, reallocated
+    // buffers.  Compared field by field (struct padding is never looked at).
+    unsigned long long generation = 0;
+    bool last_submit_graph = false;  // the last batch ran as a graph replay: no timing events were recorded
     struct GraphKey {
-        const void *frames, *depth, *right;
-        int row_stride, depth_row_stride;
-        size_t frame_stride, depth_frame_stride;
-        vo_batch_cfg cfg;
-        vo_stereo_cfg st;
-        bool packed, popcount, linked;
+        const void *frames = nullptr, *depth = nullptr, *right = nullptr;
+        int row_stride = 0, depth_row_stride = 0;
+        size_t frame_stride = 0, depth_frame_stride = 0;
+        unsigned long long generation = 0;
+        double st_baseline = 0;
+        float st_band = 0, st_min_disparity = 0, st_max_disparity = 0, st_ratio = 0;
+        bool packed = false, popcount = false;
+        bool operator==(const GraphKey &o) const
+        {
+            return frames == o.frames && depth == o.depth && right == o.right && row_stride == o.row_stride &&
+                   depth_row_stride == o.depth_row_stride && frame_stride == o.frame_stride &&
+                   depth_frame_stride == o.depth_frame_stride && generation == o.generation &&
+                   st_baseline == o.st_baseline && st_band == o.st_band && st_min_disparity == o.st_min_disparity &&
+                   st_max_disparity == o.st_max_disparity && st_ratio == o.st_ratio && packed == o.packed &&
+                   popcount == o.popcount;
+        }
     } graph_key{};
+    // forget the recorded chain; every caller that frees, reallocates or re-plans something the chain refers to
+    // goes through here
     void drop_graph()
     {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         graph_exec = nullptr;
+        generation++;
     }
 
     // optional per-stage timing of the batched pipeline (HIP events on `stream`)

@@ -93,12 +93,12 @@ int vo_knn2_hamming_static(int device, void *hip_stream, const uint8_t *query, i
                  "descriptors per set (use vo_knn2_hamming with a context for larger sets)", nq, nt, kStaticMax);
         return VO_ERR_ARG;
     }
-    if (nq == 0) return VO_OK;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail(VO_ERR_HIP, "hipSetDevice", e);
     unsigned char *base = nullptr;
-    int rc = scratch_of(device, &base);
+    int rc = scratch_of(device, &base);  // (also what a warm-up call with n_query = 0 is for)
     if (rc) return rc;
+    if (nq == 0) return VO_OK;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
 
     int *ctl = reinterpret_cast<int *>(base + kOffCtl);
