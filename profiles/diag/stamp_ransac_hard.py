@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""RANSAC stages on the moving-objects scene: distribution of the iteration counts over the frames of one launch
+and, from the diagnostic build (make -C profiles/diag), the cycle stamps of the F-RANSAC and PnP kernels.
+
+    python3 profiles/diag/stamp_ransac_hard.py [movers] [streams]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch  # first: the library must bind to the HIP runtime torch loads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from visual_odometry_amd import capi, synth  # noqa: E402
+
+
+def main():
+    diag = os.path.join(ROOT, "profiles", "diag", "libvo_hip_diag.so")
+    use_diag = os.path.exists(diag) and os.environ.get("VO_NO_DIAG", "0") != "1"
+    if use_diag:
+        capi.LIB_PATH = diag
+    lib = capi.load()
+
+    movers = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    F = 16
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    f, d, _ = synth.make_pingpong_batch(cam, S, F, 52000, channels=4, relief=2.0, movers=movers, workers=16)
+    frames = torch.from_numpy(f).cuda()
+    depth = torch.from_numpy(d).cuda()
+    ctx = capi.Context(0, cam.width, cam.height, 2064, S * F)
+    ctx.batch_configure(cam.width, cam.height, 4, S, F, max_features=2000, camera=(cam.fx, cam.fy, cam.cx, cam.cy),
+                        orb_levels=8)
+    ctx.batch_set_timing(True)
+    for _ in range(3):
+        ctx.batch_submit_ptr(frames.data_ptr(), cam.width * 4, cam.width * 4 * cam.height, depth.data_ptr(), cam.width,
+                             cam.width * cam.height)
+        res = ctx.batch_wait()
+    tm = ctx.batch_timing()
+    print("stage ms:", {k: round(v, 3) for k, v in tm.items()})
+    m = res["n_ratio"] > 0
+
+
+    def hist(name, v, bins):
+        h, _ = np.histogram(v, bins=bins)
+        print(f"{name}: mean {v.mean():.1f} max {v.max()}  hist " +
+              " ".join(f"[{bins[i]},{bins[i + 1]}):{h[i]}" for i in range(len(h))))
+
+
+    hist("ratio survivors", res["n_ratio"][m], [0, 200, 400, 600, 800, 1000, 1200, 1600, 2100])
+    hist("F iterations", res["f_iters"][m], [0, 9, 17, 33, 73, 137, 201, 329, 1001])
+    hist("PnP points", res["pnp_points"][m], [0, 100, 200, 400, 600, 800, 1000, 2100])
+    hist("PnP iterations", res["pnp_iters"][m], [0, 9, 19, 29, 39, 49, 69, 89, 101])
+
+    if use_diag:
+        raw = C.CDLL(capi.LIB_PATH)
+        pn = np.zeros((256, 16), np.uint64)
+        raw.vo_debug_pnp_stamps.argtypes = [C.c_void_p]
+        assert raw.vo_debug_pnp_stamps(pn.ctypes.data) == 0
+        t = pn[:, :11].astype(np.int64)
+        tot = t[:, 10] - t[:, 0]
+        loop = t[:, 4] - t[:, 1]
+        print("PnP blocks 0..255: whole kernel cycles median %d p90 %d max %d; RANSAC loop median %d max %d; "
+              "after the loop median %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(loop),
+                                                   loop.max(), np.median(t[:, 10] - t[:, 4]), (t[:, 10] - t[:, 4]).max()))
+        print("PnP kernel first start -> last end (blocks 0..255):", int(t[:, 10].max() - t[:, 0].min()))
+        fr = np.zeros((256, 16), np.uint64)
+        raw.vo_debug_fr_stamps.argtypes = [C.c_void_p]
+        assert raw.vo_debug_fr_stamps(fr.ctypes.data) == 0
+        t = fr[:, :10].astype(np.int64)
+        ok = t[:, 9] > 0
+        t = t[ok]
+        names = ["load points", "(earlier rounds)", "rng window", "subset attempts", "chain (one lane)", "7-point solve",
+                 "score", "accept (one lane)", "final mask + compaction"]
+        dd = np.diff(t, axis=1)
+        print("F-RANSAC blocks with stamps:", int(ok.sum()))
+        for i, n in enumerate(names):
+            print(f"{n:36s} median {np.median(dd[:, i]):9.0f}  p90 {np.percentile(dd[:, i], 90):9.0f} max {dd[:, i].max():9.0f}")
+        tot = t[:, 9] - t[:, 0]
+        print(f"{'whole kernel':36s} median {np.median(tot):9.0f} p90 {np.percentile(tot, 90):9.0f} max {tot.max():9.0f}")
+        print("F kernel first start -> last end (blocks 0..255):", int(t[:, 9].max() - t[:, 0].min()))
+
+
+if __name__ == "__main__":
+    main()

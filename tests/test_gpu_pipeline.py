@@ -48,6 +48,31 @@ def test_solve_pnp_ransac(ctx, oracle, n, outliers, noise):
             assert np.abs(rv_g - rv).max() < 5e-3 and np.abs(t_g - t).max() < 25.0  # near ground truth
 
 
+@pytest.mark.parametrize("n,outliers,iters", [
+    (300, 0.45, 100),   # bound stays near 100 after the first round: every remaining hypothesis goes to the item list
+    (300, 0.6, 100),    # the bound never drops: all 100 iterations run
+    (120, 0.35, 100),   # a dozen or two iterations: a short item list
+    (300, 0.5, 1000),   # the bound starts above what the item list holds: rounds go on in the block until it fits
+    (300, 0.2, 30),     # at most 22 iterations left after the first round
+    (300, 0.3, 18), (300, 0.3, 19),   # the smallest budgets on either side of the hand-over rule
+    (9, 0.3, 100), (7, 0.15, 100),    # tiny point sets: every draw repeats indices, RNG windows end early
+])
+def test_solve_pnp_ransac_many_hypotheses(ctx, oracle, n, outliers, iters):
+    """Frames that need more than two rounds of hypotheses leave their block and are finished by the follow-up
+    launches (work items over the whole chip, then a sequential replay): iteration count, inlier list and pose must
+    be those of the sequential algorithm."""
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    for seed in range(4):
+        rng = np.random.default_rng(1000 * n + seed)
+        X, uv, rv, t = _scene_points(rng, n, cam, outliers, 0.7)
+        ok_r, rv_r, t_r, inl_r = oracle.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy, iters=iters)
+        ok, rv_g, t_g, inl = ctx.solve_pnp_ransac(X, uv, cam.fx, cam.fy, cam.cx, cam.cy, iters=iters)
+        assert ok == ok_r
+        assert np.array_equal(inl, inl_r)
+        if ok:
+            _assert_pose_close(rv_g, t_g, rv_r, t_r)
+
+
 def _planar_points(rng, n, cam, plane, outlier_frac, noise, jitter=0.0):
     """Points on a plane z = plane(x, y) (+- jitter mm: measured depth is never exactly flat) seen from a known pose."""
     x, y = rng.uniform(-1500, 1500, n), rng.uniform(-900, 900, n)

@@ -34,6 +34,8 @@ constexpr int PR_CHUNK = PR_WAVES * PR_PER_WAVE;  // hypotheses per round
 constexpr int PR_FIRST = 8;                       // hypotheses of the first round
 constexpr int PR_WIN = PR_CHUNK * 5 + 96;         // RNG words examined per round
 constexpr int PR_NRED = 45;                       // 36 JtJ + 6 JtErr + |err|^2 (pose); 36 + 8 + 1 (homography)
+constexpr int kPnpSpecMax = 128;                  // hypotheses per frame the second launch can hold
+constexpr int kPnpItemsPerFrame = 16;             // work items (runs of up to PR_CHUNK hypotheses) per frame
 
 // ---------------------------------------------------------------------
 // small dense algebra, register resident (all indices static after unrolling)
@@ -1414,153 +1416,178 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
     }
 }
 
-// out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec
-__global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__restrict__ valid,
-                                                           const float *__restrict__ pts3,
-                                                           const int *__restrict__ bp_info, int kp_stride,
-                                                           const uint32_t *__restrict__ rng_raw, int rng_len,
-                                                           double fx, double fy, double cx, double cy,
-                                                           int max_iters, double threshold, double confidence,
-                                                           int *__restrict__ inliers, int *__restrict__ pose,
-                                                           double *__restrict__ rt)
+// ---------------------------------------------------------------------
+// Two launches for the frames that need many hypotheses.
+//
+// One block per frame runs the first round of hypotheses (most frames need no more) and, when at most one more
+// round is left, that one too.  A frame that still has more than PR_CHUNK iterations to go would keep its block --
+// and with it the whole launch -- busy for up to ten more sequential rounds on one compute unit.  Such a frame is
+// handed over instead: its block chains the RNG stream into the start positions of every hypothesis the current
+// iteration bound still admits (the bound only ever shrinks), writes them out as work items of PR_CHUNK
+// hypotheses each, and exits.  k_pnp_more then solves and scores all items of all such frames side by side on the
+// whole chip, and k_pnp_resume replays the sequential acceptance rule over the stored (model, inlier count)
+// records in RNG order, stops where the sequential algorithm stops, and refines the pose.  The hypotheses, their
+// order and the acceptance logic are those of the one-block loop, so the results are the same bit for bit; only
+// hypotheses past the final iteration bound are computed in vain.
+// ---------------------------------------------------------------------
+
+// hypothesis records of the second launch: kPnpSpecMax per frame
+struct PnpHyp {
+    double model[6];
+    int count;
+    int ok;  // 1 usable, 0 solver failed, -1 never drawn (RNG table exhausted)
+};
+// what a handed-over frame needs to go on
+struct PnpResume {
+    double best[6];
+    long long pos;  // RNG position after the last hypothesis of the work items
+    int iter, niters, max_good, n_spec;
+};
+struct PnpItem {
+    long long pos;  // RNG position of the item's first hypothesis
+    int frame, first, count, pad;
+};
+
+struct PnpArgs {
+    const vo_match *valid;
+    const float *pts3;
+    const int *bp_info;
+    int kp_stride;
+    const uint32_t *rng_raw;
+    int rng_len;
+    double fx, fy, cx, cy;
+    int max_iters;
+    double threshold, confidence;
+    int *inliers, *pose;
+    double *rt;
+    // second launch (all null: every frame finishes in its own block)
+    int *counters;  // [0] work items, [1] handed-over frames
+    PnpItem *items;
+    int *frames;
+    PnpResume *resume;
+    PnpHyp *hyp;
+};
+
+__device__ __forceinline__ void pnp_lds_views(unsigned char *s_dyn, int kp_stride, float *&obj, float *&img,
+                                              uint8_t *&msk)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
     unsigned char *dyn = s_dyn + ((sizeof(PrShared) + 15) & ~size_t(15));
-    float *obj = reinterpret_cast<float *>(dyn);                              // n x 3
-    float *img = obj + 3 * (size_t)kp_stride;                                 // n x 2
-    uint8_t *msk = reinterpret_cast<uint8_t *>(img + 2 * (size_t)kp_stride);  // n
+    obj = reinterpret_cast<float *>(dyn);                              // n x 3
+    img = obj + 3 * (size_t)kp_stride;                                 // n x 2
+    msk = reinterpret_cast<uint8_t *>(img + 2 * (size_t)kp_stride);    // n
+}
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = min(bp_info[b * 2 + 1], kp_stride);
-    const vo_match *vm = valid + (size_t)b * kp_stride;
-    const float *p3 = pts3 + (size_t)b * kp_stride * 3;
-    int *inl = inliers + (size_t)b * kp_stride;
-    int *po = pose + b * 4;
-    double *rto = rt + (size_t)b * 6;
-
-    PNP_STAMP(0);
-    if (tid < 6) rto[tid] = 0;
-    // reference src/frame_processor.cpp:176-177 asks for >= 4 points; with exactly 4 OpenCV runs its P3P solver
-    // once, without RANSAC, and reports all four as inliers
-    if (n < 5) {
-        __syncthreads();  // the zeros above land before the pose
-        if (tid == 0) {
-            int ok = 0;
-            if (n == 4) {
-                float o4[12], i4[8];
-                for (int i = 0; i < 4; i++) {
-                    o4[3 * i] = p3[3 * i]; o4[3 * i + 1] = p3[3 * i + 1]; o4[3 * i + 2] = p3[3 * i + 2];
-                    i4[2 * i] = vm[i].px; i4[2 * i + 1] = vm[i].py;
-                }
-                double R[9], t[3], rv[3];
-                if (p3p_solve4(o4, i4, fx, fy, cx, cy, R, t)) {
-                    rodrigues_m2v(R, rv);
-                    for (int i = 0; i < 3; i++) { rto[i] = rv[i]; rto[3 + i] = t[i]; }
-                    for (int i = 0; i < 4; i++) inl[i] = i;
-                    ok = 1;
-                }
-            }
-            po[0] = ok; po[1] = ok ? 4 : 0; po[2] = 0; po[3] = n;
-        }
-        return;
-    }
-    for (int i = tid; i < n; i += PR_THREADS) {
+__device__ __forceinline__ void pnp_load_points(const vo_match *vm, const float *p3, int n, float *obj, float *img,
+                                                uint8_t *msk)
+{
+    for (int i = threadIdx.x; i < n; i += PR_THREADS) {
         obj[3 * i] = p3[3 * i]; obj[3 * i + 1] = p3[3 * i + 1]; obj[3 * i + 2] = p3[3 * i + 2];
         img[2 * i] = vm[i].px; img[2 * i + 1] = vm[i].py;
         msk[i] = 0;
     }
-    if (tid == 0) {
-        S.iter = 0; S.niters = max_iters > 1 ? max_iters : 1; S.max_good = 0; S.done = 0; S.pos = 0;
+}
+
+// One window of the RNG stream from S.pos on: every offset simulated as the start of a subset draw, then one lane
+// chains offsets into up to `want` hypotheses (S.start, S.nchunk) and moves S.pos behind the last of them.
+// Every thread of the block calls it; ends with a barrier.
+__device__ __forceinline__ void pnp_chain_round(PrShared &S, int n, const uint32_t *__restrict__ rng_raw, int rng_len, int want)
+{
+    const int tid = threadIdx.x;
+    const long long pos = S.pos;
+    for (int k = tid; k < PR_WIN; k += PR_THREADS) {
+        const long long a = pos + k;
+        S.r[k] = a < rng_len ? (uint16_t)(rng_raw[a] % (uint32_t)n) : (uint16_t)0;
     }
     __syncthreads();
-    const float thr2 = (float)(threshold * threshold);
-
-    if (n == 5) {
-        // OpenCV runs the minimal solver once and reports every point as inlier
-        if (tid < 5) S.r[tid] = (uint16_t)tid;
-        if (tid == 0) S.start[0] = 0;
-        __syncthreads();
-        if (wave == 0) solve_hypothesis(S, obj, img, 0, 1, 1, fx, fy, cx, cy);
-        __syncthreads();
-        if (tid == 0) {
-            const int ok = S.ok[0];
-            if (ok) {
-                for (int i = 0; i < 6; i++) rto[i] = S.model[0][i];
-                for (int i = 0; i < 5; i++) inl[i] = i;
-            }
-            po[0] = ok; po[1] = ok ? 5 : 0; po[2] = 0; po[3] = n;
-        }
-        return;
+    for (int o = tid; o < PR_WIN; o += PR_THREADS) {
+        int idx[5];
+        int cons = draw_subset5(S.r, o, idx);
+        if (pos + o + cons > rng_len) cons = 0;
+        S.cons[o] = (uint8_t)cons;
     }
+    __syncthreads();
+    if (tid == 0) {
+        int w = 0, nc = 0;
+        while (nc < want && w < PR_WIN && S.cons[w] != 0) { S.start[nc++] = w; w += S.cons[w]; }
+        S.nchunk = nc;
+        S.pos = pos + w;
+    }
+    __syncthreads();
+}
 
-    PNP_STAMP(1);
-    // ---------------- RANSAC rounds ----------------
+// solve the S.nchunk hypotheses of the round (per_wave of them per wave) and count their inliers; ends with a barrier
+__device__ __forceinline__ void pnp_solve_score(PrShared &S, const float *obj, const float *img, int n, int per_wave, double fx,
+                                double fy, double cx, double cy, float thr2)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = S.nchunk;
+    // a wave takes part when any of its hypotheses exists
+    if (wave * per_wave < nc) solve_hypothesis(S, obj, img, wave * per_wave, per_wave, nc, fx, fy, cx, cy);
+    __syncthreads();
+    PNP_STAMP(3);
+    for (int h = wave; h < nc; h += PR_WAVES) {
+        if (!S.ok[h]) continue;
+        double R[9];
+        rodrigues_v2m(S.model[h], R, nullptr);
+        const double t[3] = {S.model[h][3], S.model[h][4], S.model[h][5]};
+        int cnt = 0;
+        for (int i = lane; i < n; i += kWave)
+            cnt += (pnp_error(obj + 3 * i, img + 2 * i, R, t, fx, fy, cx, cy) <= thr2);
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) S.counts[h] = cnt;
+    }
+    __syncthreads();
+}
+
+// the sequential acceptance rule of cv::RANSACPointSetRegistrator::run for one hypothesis (one lane)
+__device__ __forceinline__ bool pnp_accept(PrShared &S, int ok, int goodc, int n, double confidence)
+{
+    const bool take = ok && goodc > max(S.max_good, 4);  // the caller copies the model into S.best
+    if (take) {
+        S.max_good = goodc;
+        S.niters = pnp_update_num_iters(confidence, (double)(n - goodc) / n, 5, S.niters);
+    }
+    S.iter++;
+    return take;
+}
+
+// RANSAC rounds from the state in S (iter, niters, max_good, best, pos) until the iteration bound is reached
+// (S.done = 1) or, with `handover`, until a frame with more than one round to go should leave its block (S.done = 2)
+__device__ __forceinline__ void pnp_ransac_rounds(PrShared &S, const float *obj, const float *img, int n, const PnpArgs &a, float thr2,
+                                  bool handover)
+{
+    const int tid = threadIdx.x;
     while (true) {
-        const long long pos = S.pos;
-        for (int k = tid; k < PR_WIN; k += PR_THREADS) {
-            const long long a = pos + k;
-            S.r[k] = a < rng_len ? (uint16_t)(rng_raw[a] % (uint32_t)n) : (uint16_t)0;
-        }
-        __syncthreads();
-        for (int o = tid; o < PR_WIN; o += PR_THREADS) {
-            int idx[5];
-            int cons = draw_subset5(S.r, o, idx);
-            if (pos + o + cons > rng_len) cons = 0;
-            S.cons[o] = (uint8_t)cons;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int w = 0, nc = 0;
-            // the first round is the only one of most frames: four hypotheses per wave (a wave's decomposition
-            // takes as many sweeps as its slowest group needs); later rounds fill all five groups of a wave
-            S.per_wave = S.iter == 0 ? PR_FIRST / PR_WAVES : PR_PER_WAVE;
-            const int want = min(S.per_wave * PR_WAVES, S.niters - S.iter);
-            while (nc < want && w < PR_WIN && S.cons[w] != 0) { S.start[nc++] = w; w += S.cons[w]; }
-            S.nchunk = nc;
-            S.pos = pos + w;
-            if (nc == 0) S.done = 1;  // RNG table exhausted
-        }
-        __syncthreads();
+        // the first round is the only one of most frames: four hypotheses per wave (a wave's decomposition
+        // takes as many sweeps as its slowest group needs); later rounds fill all five groups of a wave
+        const int pw = S.iter == 0 ? PR_FIRST / PR_WAVES : PR_PER_WAVE;
+        const int want = min(pw * PR_WAVES, S.niters - S.iter);
+        pnp_chain_round(S, n, a.rng_raw, a.rng_len, want);
         PNP_STAMP(2);
         const int nc = S.nchunk;
-        // a wave takes part when any of its hypotheses exists
-        const int pw = S.per_wave;
-        if (wave * pw < nc) solve_hypothesis(S, obj, img, wave * pw, pw, nc, fx, fy, cx, cy);
-        __syncthreads();
-        PNP_STAMP(3);
-        for (int h = wave; h < nc; h += PR_WAVES) {
-            if (!S.ok[h]) continue;
-            double R[9];
-            rodrigues_v2m(S.model[h], R, nullptr);
-            const double t[3] = {S.model[h][3], S.model[h][4], S.model[h][5]};
-            int cnt = 0;
-            for (int i = lane; i < n; i += kWave)
-                cnt += (pnp_error(obj + 3 * i, img + 2 * i, R, t, fx, fy, cx, cy) <= thr2);
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-            if (lane == 0) S.counts[h] = cnt;
-        }
-        __syncthreads();
+        pnp_solve_score(S, obj, img, n, pw, a.fx, a.fy, a.cx, a.cy, thr2);
         if (tid == 0) {
+            if (nc == 0) S.done = 1;  // RNG table exhausted
             for (int h = 0; h < nc; h++) {
-                if (S.ok[h]) {
-                    const int goodc = S.counts[h];
-                    if (goodc > max(S.max_good, 4)) {
-                        for (int i = 0; i < 6; i++) S.best[i] = S.model[h][i];
-                        S.max_good = goodc;
-                        S.niters = pnp_update_num_iters(confidence, (double)(n - goodc) / n, 5, S.niters);
-                    }
-                }
-                S.iter++;
+                if (pnp_accept(S, S.ok[h], S.counts[h], n, a.confidence))
+                    for (int i = 0; i < 6; i++) S.best[i] = S.model[h][i];
                 if (S.iter >= S.niters) break;
             }
             if (S.iter >= S.niters) S.done = 1;
+            else if (handover && !S.done && S.niters - S.iter > PR_CHUNK && S.niters - S.iter <= kPnpSpecMax)
+                S.done = 2;
         }
         __syncthreads();
         PNP_STAMP(4);
         if (S.done) break;
     }
+}
 
+// after the RANSAC rounds: inlier list of the best hypothesis, solvePnP(SOLVEPNP_ITERATIVE) on the inliers, outputs
+__device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const float *img, uint8_t *msk, int n, double fx, double fy,
+                           double cx, double cy, float thr2, int *inl, int *po, double *rto)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool found = S.max_good > 0;
     if (!found) {
         if (tid == 0) { po[0] = 0; po[1] = 0; po[2] = S.iter; po[3] = n; }
@@ -1848,16 +1875,227 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(const vo_match *__res
     }
 }
 
+// out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec
+__global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
+    float *obj, *img;
+    uint8_t *msk;
+    pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
+
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int kp_stride = a.kp_stride;
+    const int n = min(a.bp_info[b * 2 + 1], kp_stride);
+    const vo_match *vm = a.valid + (size_t)b * kp_stride;
+    const float *p3 = a.pts3 + (size_t)b * kp_stride * 3;
+    int *inl = a.inliers + (size_t)b * kp_stride;
+    int *po = a.pose + b * 4;
+    double *rto = a.rt + (size_t)b * 6;
+    const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+
+    PNP_STAMP(0);
+    if (tid < 6) rto[tid] = 0;
+    // reference src/frame_processor.cpp:176-177 asks for >= 4 points; with exactly 4 OpenCV runs its P3P solver
+    // once, without RANSAC, and reports all four as inliers
+    if (n < 5) {
+        __syncthreads();  // the zeros above land before the pose
+        if (tid == 0) {
+            int ok = 0;
+            if (n == 4) {
+                float o4[12], i4[8];
+                for (int i = 0; i < 4; i++) {
+                    o4[3 * i] = p3[3 * i]; o4[3 * i + 1] = p3[3 * i + 1]; o4[3 * i + 2] = p3[3 * i + 2];
+                    i4[2 * i] = vm[i].px; i4[2 * i + 1] = vm[i].py;
+                }
+                double R[9], t[3], rv[3];
+                if (p3p_solve4(o4, i4, fx, fy, cx, cy, R, t)) {
+                    rodrigues_m2v(R, rv);
+                    for (int i = 0; i < 3; i++) { rto[i] = rv[i]; rto[3 + i] = t[i]; }
+                    for (int i = 0; i < 4; i++) inl[i] = i;
+                    ok = 1;
+                }
+            }
+            po[0] = ok; po[1] = ok ? 4 : 0; po[2] = 0; po[3] = n;
+        }
+        return;
+    }
+    pnp_load_points(vm, p3, n, obj, img, msk);
+    if (tid == 0) {
+        S.iter = 0; S.niters = a.max_iters > 1 ? a.max_iters : 1; S.max_good = 0; S.done = 0; S.pos = 0;
+    }
+    __syncthreads();
+    const float thr2 = (float)(a.threshold * a.threshold);
+
+    if (n == 5) {
+        // OpenCV runs the minimal solver once and reports every point as inlier
+        if (tid < 5) S.r[tid] = (uint16_t)tid;
+        if (tid == 0) S.start[0] = 0;
+        __syncthreads();
+        if (wave == 0) solve_hypothesis(S, obj, img, 0, 1, 1, fx, fy, cx, cy);
+        __syncthreads();
+        if (tid == 0) {
+            const int ok = S.ok[0];
+            if (ok) {
+                for (int i = 0; i < 6; i++) rto[i] = S.model[0][i];
+                for (int i = 0; i < 5; i++) inl[i] = i;
+            }
+            po[0] = ok; po[1] = ok ? 5 : 0; po[2] = 0; po[3] = n;
+        }
+        return;
+    }
+
+    PNP_STAMP(1);
+    pnp_ransac_rounds(S, obj, img, n, a, thr2, a.counters != nullptr);
+
+    if (S.done == 2) {
+        // hand the frame over: chain the RNG stream into work items of up to PR_CHUNK hypotheses covering the
+        // iterations the current bound still admits (a window that ends early yields a shorter item)
+        const int want_all = S.niters - S.iter;
+        int covered = 0, n_items = 0;
+        const int slot = tid == 0 ? atomicAdd(&a.counters[1], 1) : 0;
+        PnpItem *mine = a.items + (size_t)b * kPnpItemsPerFrame;
+        PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
+        while (covered < want_all && n_items < kPnpItemsPerFrame) {
+            const long long pos0 = S.pos;
+            pnp_chain_round(S, n, a.rng_raw, a.rng_len, min(PR_CHUNK, want_all - covered));
+            const int nc = S.nchunk;
+            if (nc == 0) break;  // RNG table exhausted: the resumed loop finds that out again
+            if (tid == 0) mine[n_items] = PnpItem{pos0, b, covered, nc, 0};
+            covered += nc;
+            n_items++;
+        }
+        for (int h = tid; h < covered; h += PR_THREADS) hy[h].ok = -1;
+        if (tid == 0) {
+            PnpResume &r = a.resume[b];
+            for (int i = 0; i < 6; i++) r.best[i] = S.best[i];
+            r.pos = S.pos; r.iter = S.iter; r.niters = S.niters; r.max_good = S.max_good; r.n_spec = covered;
+            a.frames[slot] = b;
+            // the items of this frame become visible to the next launch through the list of item references
+            const int first = atomicAdd(&a.counters[0], n_items);
+            int *refs = reinterpret_cast<int *>(a.items + (size_t)gridDim.x * kPnpItemsPerFrame);
+            for (int i = 0; i < n_items; i++) refs[first + i] = b * kPnpItemsPerFrame + i;
+        }
+        return;
+    }
+    pnp_finish(S, obj, img, msk, n, fx, fy, cx, cy, thr2, inl, po, rto);
+}
+
+// second launch, part one: every work item (a run of up to PR_CHUNK hypotheses of one handed-over frame) solved and
+// scored by one block; blocks walk the item list with a grid stride
+__global__ __launch_bounds__(PR_THREADS) void k_pnp_more(PnpArgs a, int batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
+    float *obj, *img;
+    uint8_t *msk;
+    pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
+    const int tid = threadIdx.x;
+    const int n_work = a.counters[0];
+    const int *refs = reinterpret_cast<const int *>(a.items + (size_t)batch * kPnpItemsPerFrame);
+    const float thr2 = (float)(a.threshold * a.threshold);
+    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const PnpItem it = a.items[refs[w]];
+        const int b = it.frame;
+        const int n = min(a.bp_info[b * 2 + 1], a.kp_stride);
+        __syncthreads();  // the previous item's points are no longer read
+        pnp_load_points(a.valid + (size_t)b * a.kp_stride, a.pts3 + (size_t)b * a.kp_stride * 3, n, obj, img, msk);
+        if (tid == 0) S.pos = it.pos;
+        __syncthreads();
+        pnp_chain_round(S, n, a.rng_raw, a.rng_len, it.count);
+        pnp_solve_score(S, obj, img, n, PR_PER_WAVE, a.fx, a.fy, a.cx, a.cy, thr2);
+        const int nc = S.nchunk;  // == it.count: the same window, the same chain
+        PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax + it.first;
+        if (tid < nc) {
+            const int ok = S.ok[tid];
+            for (int i = 0; i < 6; i++) hy[tid].model[i] = ok ? S.model[tid][i] : 0.0;
+            hy[tid].count = ok ? S.counts[tid] : 0;
+            hy[tid].ok = ok ? 1 : 0;
+        }
+    }
+}
+
+// second launch, part two: one block per handed-over frame replays the acceptance rule over the stored hypotheses
+// in RNG order, runs whatever the sequential algorithm still asks for, and refines
+__global__ __launch_bounds__(PR_THREADS) void k_pnp_resume(PnpArgs a)
+{
+    if ((int)blockIdx.x >= a.counters[1]) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
+    float *obj, *img;
+    uint8_t *msk;
+    pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
+    const int tid = threadIdx.x;
+    const int b = a.frames[blockIdx.x];
+    const int kp_stride = a.kp_stride;
+    const int n = min(a.bp_info[b * 2 + 1], kp_stride);
+    pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img, msk);
+    const float thr2 = (float)(a.threshold * a.threshold);
+    if (tid == 0) {
+        const PnpResume &r = a.resume[b];
+        for (int i = 0; i < 6; i++) S.best[i] = r.best[i];
+        S.pos = r.pos; S.iter = r.iter; S.niters = r.niters; S.max_good = r.max_good; S.done = 0;
+        const PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
+        for (int h = 0; h < r.n_spec; h++) {
+            if (hy[h].ok < 0) break;  // (never written: cannot happen while the item list is complete)
+            if (pnp_accept(S, hy[h].ok, hy[h].count, n, a.confidence))
+                for (int i = 0; i < 6; i++) S.best[i] = hy[h].model[i];
+            if (S.iter >= S.niters) { S.done = 1; break; }
+        }
+    }
+    __syncthreads();
+    // the stored hypotheses cover the iteration bound the frame left with, and the bound only shrinks: normally
+    // nothing is left; a shortened item list (RNG window ends, item capacity) continues here
+    if (!S.done) pnp_ransac_rounds(S, obj, img, n, a, thr2, false);
+    pnp_finish(S, obj, img, msk, n, a.fx, a.fy, a.cx, a.cy, thr2, a.inliers + (size_t)b * kp_stride, a.pose + b * 4,
+               a.rt + (size_t)b * 6);
+}
+
+size_t pnp_phase2_bytes(int batch, size_t off[5])
+{
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~size_t(255); return at; };
+    off[0] = take(2 * sizeof(int));                                                       // counters
+    off[1] = take((sizeof(PnpItem) + sizeof(int)) * (size_t)batch * kPnpItemsPerFrame);   // items, then item refs
+    off[2] = take(sizeof(int) * (size_t)batch);                                           // frames
+    off[3] = take(sizeof(PnpResume) * (size_t)batch);                                     // resume
+    off[4] = take(sizeof(PnpHyp) * (size_t)batch * kPnpSpecMax);                          // hyp
+    return o;
+}
+
 void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_info, int kp_stride,
                        const uint32_t *rng_raw, int rng_len, double fx, double fy, double cx, double cy,
                        int max_iters, double threshold, double confidence, int *inliers, int *pose,
-                       double *rt, int batch, hipStream_t s)
+                       double *rt, int batch, void *phase2, hipStream_t s)
 {
     const size_t lds = ((sizeof(PrShared) + 15) & ~size_t(15)) + (size_t)kp_stride * (5 * sizeof(float) + 1) + 16;
+    PnpArgs a{valid, pts3, bp_info, kp_stride, rng_raw, rng_len, fx, fy, cx, cy, max_iters, threshold, confidence,
+              inliers, pose, rt, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // the second launch pays when hypotheses can outnumber two rounds; its buffers hold kPnpSpecMax per frame
+    const bool two = phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
+    if (two) {
+        size_t off[5];
+        (void)pnp_phase2_bytes(batch, off);
+        unsigned char *p = static_cast<unsigned char *>(phase2);
+        a.counters = reinterpret_cast<int *>(p + off[0]);
+        a.items = reinterpret_cast<PnpItem *>(p + off[1]);
+        a.frames = reinterpret_cast<int *>(p + off[2]);
+        a.resume = reinterpret_cast<PnpResume *>(p + off[3]);
+        a.hyp = reinterpret_cast<PnpHyp *>(p + off[4]);
+        (void)hipMemsetAsync(a.counters, 0, 2 * sizeof(int), s);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_ransac),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_pnp_ransac, dim3(batch), dim3(PR_THREADS), lds, s, valid, pts3, bp_info, kp_stride,
-                       rng_raw, rng_len, fx, fy, cx, cy, max_iters, threshold, confidence, inliers, pose, rt);
+    hipLaunchKernelGGL(k_pnp_ransac, dim3(batch), dim3(PR_THREADS), lds, s, a);
+    if (two) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_more),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_resume),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const int grid = min(1024, batch * kPnpItemsPerFrame);
+        hipLaunchKernelGGL(k_pnp_more, dim3(grid), dim3(PR_THREADS), lds, s, a, batch);
+        hipLaunchKernelGGL(k_pnp_resume, dim3(batch), dim3(PR_THREADS), lds, s, a);
+    }
 }
 
 }  // namespace vo

@@ -197,7 +197,7 @@ int vo_solve_pnp_ransac(vo_ctx *c, const float *obj, const float *img, int n, do
     }
     HIP_TRY(c, hipMemcpy(c->d_bpinfo, bp, sizeof(bp), hipMemcpyHostToDevice));
     launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, fx, fy, cx, cy,
-                      iters, thr, conf, c->d_inliers, c->d_pose, c->d_rt, 1, c->stream);
+                      iters, thr, conf, c->d_inliers, c->d_pose, c->d_rt, 1, c->d_pnp2, c->stream);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_solve_pnp_ransac: %s", hipGetErrorString(e));
@@ -464,7 +464,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         } else
             launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
                               b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
-                              c->d_rt, B, c->stream);
+                              c->d_rt, B, c->d_pnp2, c->stream);
         c->mark(11);
         launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
                        c->stream);

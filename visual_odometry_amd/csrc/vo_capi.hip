@@ -160,6 +160,10 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMalloc(&d_pose, sizeof(int) * 4 * B));
     HIP_TRY(ctx, hipMalloc(&d_rt, sizeof(double) * 6 * B));
     HIP_TRY(ctx, hipMalloc(&d_results, sizeof(vo_frame_result) * B));
+    {
+        size_t off[5];
+        HIP_TRY(ctx, hipMalloc(&d_pnp2, pnp_phase2_bytes(B, off)));
+    }
     HIP_TRY(ctx, hipMemset(d_ages, 0, sizeof(int) * (size_t)kp_stride * slots));
     HIP_TRY(ctx, hipMemset(d_pose, 0, sizeof(int) * 4 * B));
     HIP_TRY(ctx, hipMemset(d_rt, 0, sizeof(double) * 6 * B));
@@ -204,7 +208,7 @@ void vo_ctx::release()
                     d_st_idx, d_st_disp, d_st_depth, d_st_plane, d_st_n,
                     d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
-                    d_inliers, d_pose, d_rt, d_results};
+                    d_inliers, d_pose, d_rt, d_results, d_pnp2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : ev)

@@ -82,6 +82,7 @@ struct vo_ctx {
     float *d_pts3 = nullptr;
     int *d_bpinfo = nullptr, *d_inliers = nullptr, *d_pose = nullptr;
     double *d_rt = nullptr;
+    void *d_pnp2 = nullptr;    // scratch of the PnP stage's follow-up launches (pnp_phase2_bytes(max_batch))
     vo_frame_result *d_results = nullptr;
 
     // batched pipeline state
