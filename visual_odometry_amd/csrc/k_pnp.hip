@@ -685,6 +685,8 @@ struct PrShared {
     long long pos;
     int scan_base;
     int lm_ok;
+    int cand, claim_item, claim_n, last;   // claiming published work items
+    unsigned long long acc_mask[PR_WAVES];  // accepted hypotheses of a replay
     // planar initialisation (homography) of the refinement
     int init_mode;        // 0 DLT, 1 homography (planar inliers), 2 five non-planar inliers: keep the RANSAC pose
     int h_flag;           // block-uniform decisions of the homography polish
@@ -1417,25 +1419,28 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
 }
 
 // ---------------------------------------------------------------------
-// Two launches for the frames that need many hypotheses.
+// Frames that need many hypotheses are spread over the chip.
 //
 // One block per frame runs the first round of hypotheses (most frames need no more) and, when at most one more
 // round is left, that one too.  A frame that still has more than PR_CHUNK iterations to go would keep its block --
 // and with it the whole launch -- busy for up to ten more sequential rounds on one compute unit.  Such a frame is
 // handed over instead: its block chains the RNG stream into the start positions of every hypothesis the current
-// iteration bound still admits (the bound only ever shrinks), writes them out as work items of PR_CHUNK
-// hypotheses each, and exits.  k_pnp_more then solves and scores all items of all such frames side by side on the
-// whole chip, and k_pnp_resume replays the sequential acceptance rule over the stored (model, inlier count)
-// records in RNG order, stops where the sequential algorithm stops, and refines the pose.  The hypotheses, their
-// order and the acceptance logic are those of the one-block loop, so the results are the same bit for bit; only
-// hypotheses past the final iteration bound are computed in vain.
+// iteration bound still admits (the bound only ever shrinks), publishes them as work items of up to PR_CHUNK
+// hypotheses, and looks for work itself.  Every block whose own frame is finished claims published items (of any
+// frame), solves and scores their hypotheses and stores (model, inlier count) records; the block that completes a
+// frame's last item replays the sequential acceptance rule over the records in RNG order, stops where the
+// sequential algorithm stops, and refines the pose.  Blocks never wait for each other: a block that finds nothing
+// to claim exits, and a second launch of the same kernel (without frames of its own) sweeps up whatever was
+// published after the last block looked.  The hypotheses, their order and the acceptance logic are those of the
+// one-block loop, so the results are the same bit for bit; only hypotheses past the final iteration bound are
+// computed in vain.
 // ---------------------------------------------------------------------
 
-// hypothesis records of the second launch: kPnpSpecMax per frame
+// hypothesis records of a handed-over frame: kPnpSpecMax per frame
 struct PnpHyp {
     double model[6];
     int count;
-    int ok;  // 1 usable, 0 solver failed, -1 never drawn (RNG table exhausted)
+    int ok;  // 1 usable, 0 the solver failed
 };
 // what a handed-over frame needs to go on
 struct PnpResume {
@@ -1445,7 +1450,7 @@ struct PnpResume {
 };
 struct PnpItem {
     long long pos;  // RNG position of the item's first hypothesis
-    int frame, first, count, pad;
+    int first, count;
 };
 
 struct PnpArgs {
@@ -1460,10 +1465,12 @@ struct PnpArgs {
     double threshold, confidence;
     int *inliers, *pose;
     double *rt;
-    // second launch (all null: every frame finishes in its own block)
-    int *counters;  // [0] work items, [1] handed-over frames
-    PnpItem *items;
-    int *frames;
+    int batch;
+    // hand-over (all null: every frame finishes in its own block).  Per frame: state = number of published items
+    // (0 until the frame's items, resume record and everything else are in memory), next = items claimed so far
+    // (may overshoot), done = items completed.  Zero before the first launch.
+    int *state, *next, *done;
+    PnpItem *items;  // kPnpItemsPerFrame per frame
     PnpResume *resume;
     PnpHyp *hyp;
 };
@@ -1875,8 +1882,128 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
     }
 }
 
-// out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec
-__global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a)
+// Hand the frame in S over: chain the RNG stream into work items of up to PR_CHUNK hypotheses covering the
+// iterations the current bound still admits (a window that ends early yields a shorter item) and publish them.
+// False when not a single hypothesis could be chained (RNG table exhausted): the caller finishes the frame itself.
+__device__ __forceinline__ bool pnp_publish_items(PrShared &S, const PnpArgs &a, int b, int n)
+{
+    const int tid = threadIdx.x;
+    const int want_all = S.niters - S.iter;
+    int covered = 0, n_items = 0;
+    PnpItem *mine = a.items + (size_t)b * kPnpItemsPerFrame;
+    while (covered < want_all && n_items < kPnpItemsPerFrame) {
+        const long long pos0 = S.pos;
+        pnp_chain_round(S, n, a.rng_raw, a.rng_len, min(PR_CHUNK, want_all - covered));
+        const int nc = S.nchunk;
+        if (nc == 0) break;
+        if (tid == 0) mine[n_items] = PnpItem{pos0, covered, nc};
+        covered += nc;
+        n_items++;
+    }
+    if (n_items == 0) return false;
+    if (tid == 0) {
+        PnpResume &r = a.resume[b];
+        for (int i = 0; i < 6; i++) r.best[i] = S.best[i];
+        r.pos = S.pos; r.iter = S.iter; r.niters = S.niters; r.max_good = S.max_good; r.n_spec = covered;
+        __threadfence();  // items and resume record before the word that announces them
+        __hip_atomic_store(&a.state[b], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
+// Claim one published work item: the frame nearest to this block's own (in cyclic order) that still has unclaimed
+// items.  Returns the frame (item index and item count of the frame in S.claim_item / S.claim_n) or -1 when nothing
+// is on offer.  Every thread calls it.
+__device__ __forceinline__ int pnp_claim(PrShared &S, const PnpArgs &a)
+{
+    const int tid = threadIdx.x;
+    for (;;) {
+        if (tid == 0) S.cand = 0x7fffffff;
+        __syncthreads();
+        for (int k = tid; k < a.batch; k += PR_THREADS) {
+            int bb = (int)blockIdx.x + k;
+            if (bb >= a.batch) bb -= a.batch;
+            const int st = __hip_atomic_load(&a.state[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (st > 0 && __hip_atomic_load(&a.next[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < st)
+                atomicMin(&S.cand, k);
+        }
+        __syncthreads();
+        const int k = S.cand;
+        if (k == 0x7fffffff) return -1;
+        int bb = (int)blockIdx.x + k;
+        if (bb >= a.batch) bb -= a.batch;
+        if (tid == 0) {
+            const int st = __hip_atomic_load(&a.state[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int i = atomicAdd(&a.next[bb], 1);
+            S.claim_item = i < st ? i : -1;  // somebody else took the last one in between: look again
+            S.claim_n = st;
+            __threadfence();  // what the publisher wrote before `state` is read after this
+        }
+        __syncthreads();
+        if (S.claim_item >= 0) return bb;
+    }
+}
+
+// Replay of cv::RANSACPointSetRegistrator::run's acceptance rule over the n_spec stored hypotheses of frame b, in
+// RNG order: a hypothesis is accepted when its count beats every earlier one (a prefix maximum, found by all
+// threads at once); one lane then walks the accepted ones, moving the iteration bound, and finds the index at
+// which the sequential loop would have stopped.  Leaves S as that loop would (S.done = 1 when it stopped inside the
+// stored hypotheses).  Every thread calls it; ends with a barrier.
+__device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b, int n)
+{
+    static_assert(kPnpSpecMax <= PR_THREADS, "one stored hypothesis per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PnpResume r = a.resume[b];
+    const PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
+    int c = -1;
+    if (tid < r.n_spec && hy[tid].ok > 0) c = hy[tid].count;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off);
+        if (lane >= off) incl = max(incl, y);
+    }
+    if (lane == 63) S.wave_tot[wave] = incl;
+    int excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -1;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) excl = max(excl, S.wave_tot[w]);
+    const bool acc = c > max(excl, max(r.max_good, 4));
+    const unsigned long long bm = __ballot(acc);
+    if (lane == 0) S.acc_mask[wave] = bm;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < 6; i++) S.best[i] = r.best[i];
+        int N = r.niters, max_good = r.max_good;
+        int prev = 0, final_iter = r.iter + r.n_spec;
+        bool done = false;
+        // between two accepted hypotheses the bound N is constant: the loop stops at the first index j of the
+        // stretch with iter + 1 = r.iter + j + 1 >= N
+        for (int w = 0; w < PR_WAVES && !done; w++) {
+            unsigned long long m = S.acc_mask[w];
+            while (m) {
+                const int h = w * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = max(prev, N - r.iter - 1);
+                if (j <= h - 1) { done = true; final_iter = r.iter + j + 1; break; }
+                for (int i = 0; i < 6; i++) S.best[i] = hy[h].model[i];
+                max_good = hy[h].count;
+                N = pnp_update_num_iters(a.confidence, (double)(n - max_good) / n, 5, N);
+                prev = h;
+            }
+        }
+        if (!done) {
+            const int j = max(prev, N - r.iter - 1);
+            if (j <= r.n_spec - 1) { done = true; final_iter = r.iter + j + 1; }
+        }
+        S.pos = r.pos; S.iter = final_iter; S.niters = N; S.max_good = max_good; S.done = done ? 1 : 0;
+    }
+    __syncthreads();
+}
+
+// out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec.
+// sweep = 0: block b owns frame b, then helps with published work items; sweep = 1: published work items only.
+__global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
@@ -1884,182 +2011,132 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a)
     uint8_t *msk;
     pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
 
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int kp_stride = a.kp_stride;
-    const int n = min(a.bp_info[b * 2 + 1], kp_stride);
-    const vo_match *vm = a.valid + (size_t)b * kp_stride;
-    const float *p3 = a.pts3 + (size_t)b * kp_stride * 3;
-    int *inl = a.inliers + (size_t)b * kp_stride;
-    int *po = a.pose + b * 4;
-    double *rto = a.rt + (size_t)b * 6;
     const double fx = a.fx, fy = a.fy, cx = a.cx, cy = a.cy;
+    const float thr2 = (float)(a.threshold * a.threshold);
+    const bool share = a.state != nullptr;
+    int b = blockIdx.x;  // the frame whose points are in LDS and whose RANSAC state is in S
+    int n = 0;
+    bool run = false;    // that frame is to be driven to its end by this block
+    bool own = false;    // ... and it is this block's own frame (it may still be handed over)
 
     PNP_STAMP(0);
-    if (tid < 6) rto[tid] = 0;
-    // reference src/frame_processor.cpp:176-177 asks for >= 4 points; with exactly 4 OpenCV runs its P3P solver
-    // once, without RANSAC, and reports all four as inliers
-    if (n < 5) {
-        __syncthreads();  // the zeros above land before the pose
-        if (tid == 0) {
-            int ok = 0;
-            if (n == 4) {
-                float o4[12], i4[8];
-                for (int i = 0; i < 4; i++) {
-                    o4[3 * i] = p3[3 * i]; o4[3 * i + 1] = p3[3 * i + 1]; o4[3 * i + 2] = p3[3 * i + 2];
-                    i4[2 * i] = vm[i].px; i4[2 * i + 1] = vm[i].py;
+    if (!sweep) {
+        n = min(a.bp_info[b * 2 + 1], kp_stride);
+        const vo_match *vm = a.valid + (size_t)b * kp_stride;
+        const float *p3 = a.pts3 + (size_t)b * kp_stride * 3;
+        int *inl = a.inliers + (size_t)b * kp_stride;
+        int *po = a.pose + b * 4;
+        double *rto = a.rt + (size_t)b * 6;
+        if (tid < 6) rto[tid] = 0;
+        // reference src/frame_processor.cpp:176-177 asks for >= 4 points; with exactly 4 OpenCV runs its P3P
+        // solver once, without RANSAC, and reports all four as inliers
+        if (n < 5) {
+            __syncthreads();  // the zeros above land before the pose
+            if (tid == 0) {
+                int ok = 0;
+                if (n == 4) {
+                    float o4[12], i4[8];
+                    for (int i = 0; i < 4; i++) {
+                        o4[3 * i] = p3[3 * i]; o4[3 * i + 1] = p3[3 * i + 1]; o4[3 * i + 2] = p3[3 * i + 2];
+                        i4[2 * i] = vm[i].px; i4[2 * i + 1] = vm[i].py;
+                    }
+                    double R[9], t[3], rv[3];
+                    if (p3p_solve4(o4, i4, fx, fy, cx, cy, R, t)) {
+                        rodrigues_m2v(R, rv);
+                        for (int i = 0; i < 3; i++) { rto[i] = rv[i]; rto[3 + i] = t[i]; }
+                        for (int i = 0; i < 4; i++) inl[i] = i;
+                        ok = 1;
+                    }
                 }
-                double R[9], t[3], rv[3];
-                if (p3p_solve4(o4, i4, fx, fy, cx, cy, R, t)) {
-                    rodrigues_m2v(R, rv);
-                    for (int i = 0; i < 3; i++) { rto[i] = rv[i]; rto[3 + i] = t[i]; }
-                    for (int i = 0; i < 4; i++) inl[i] = i;
-                    ok = 1;
-                }
+                po[0] = ok; po[1] = ok ? 4 : 0; po[2] = 0; po[3] = n;
             }
-            po[0] = ok; po[1] = ok ? 4 : 0; po[2] = 0; po[3] = n;
+            return;
         }
-        return;
-    }
-    pnp_load_points(vm, p3, n, obj, img, msk);
-    if (tid == 0) {
-        S.iter = 0; S.niters = a.max_iters > 1 ? a.max_iters : 1; S.max_good = 0; S.done = 0; S.pos = 0;
-    }
-    __syncthreads();
-    const float thr2 = (float)(a.threshold * a.threshold);
+        pnp_load_points(vm, p3, n, obj, img, msk);
+        if (tid == 0) {
+            S.iter = 0; S.niters = a.max_iters > 1 ? a.max_iters : 1; S.max_good = 0; S.done = 0; S.pos = 0;
+        }
+        __syncthreads();
 
-    if (n == 5) {
-        // OpenCV runs the minimal solver once and reports every point as inlier
-        if (tid < 5) S.r[tid] = (uint16_t)tid;
-        if (tid == 0) S.start[0] = 0;
-        __syncthreads();
-        if (wave == 0) solve_hypothesis(S, obj, img, 0, 1, 1, fx, fy, cx, cy);
-        __syncthreads();
-        if (tid == 0) {
-            const int ok = S.ok[0];
-            if (ok) {
-                for (int i = 0; i < 6; i++) rto[i] = S.model[0][i];
-                for (int i = 0; i < 5; i++) inl[i] = i;
+        if (n == 5) {
+            // OpenCV runs the minimal solver once and reports every point as inlier
+            if (tid < 5) S.r[tid] = (uint16_t)tid;
+            if (tid == 0) S.start[0] = 0;
+            __syncthreads();
+            if (wave == 0) solve_hypothesis(S, obj, img, 0, 1, 1, fx, fy, cx, cy);
+            __syncthreads();
+            if (tid == 0) {
+                const int ok = S.ok[0];
+                if (ok) {
+                    for (int i = 0; i < 6; i++) rto[i] = S.model[0][i];
+                    for (int i = 0; i < 5; i++) inl[i] = i;
+                }
+                po[0] = ok; po[1] = ok ? 5 : 0; po[2] = 0; po[3] = n;
             }
-            po[0] = ok; po[1] = ok ? 5 : 0; po[2] = 0; po[3] = n;
+            return;
         }
-        return;
+        run = own = true;
     }
 
     PNP_STAMP(1);
-    pnp_ransac_rounds(S, obj, img, n, a, thr2, a.counters != nullptr);
-
-    if (S.done == 2) {
-        // hand the frame over: chain the RNG stream into work items of up to PR_CHUNK hypotheses covering the
-        // iterations the current bound still admits (a window that ends early yields a shorter item)
-        const int want_all = S.niters - S.iter;
-        int covered = 0, n_items = 0;
-        const int slot = tid == 0 ? atomicAdd(&a.counters[1], 1) : 0;
-        PnpItem *mine = a.items + (size_t)b * kPnpItemsPerFrame;
-        PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
-        while (covered < want_all && n_items < kPnpItemsPerFrame) {
-            const long long pos0 = S.pos;
-            pnp_chain_round(S, n, a.rng_raw, a.rng_len, min(PR_CHUNK, want_all - covered));
-            const int nc = S.nchunk;
-            if (nc == 0) break;  // RNG table exhausted: the resumed loop finds that out again
-            if (tid == 0) mine[n_items] = PnpItem{pos0, b, covered, nc, 0};
-            covered += nc;
-            n_items++;
+    for (;;) {
+        if (run) {
+            if (!S.done) pnp_ransac_rounds(S, obj, img, n, a, thr2, own && share);
+            bool handed = false;
+            if (S.done == 2) handed = pnp_publish_items(S, a, b, n);
+            if (!handed)
+                pnp_finish(S, obj, img, msk, n, fx, fy, cx, cy, thr2, a.inliers + (size_t)b * kp_stride,
+                           a.pose + b * 4, a.rt + (size_t)b * 6);
+            run = own = false;
         }
-        for (int h = tid; h < covered; h += PR_THREADS) hy[h].ok = -1;
-        if (tid == 0) {
-            PnpResume &r = a.resume[b];
-            for (int i = 0; i < 6; i++) r.best[i] = S.best[i];
-            r.pos = S.pos; r.iter = S.iter; r.niters = S.niters; r.max_good = S.max_good; r.n_spec = covered;
-            a.frames[slot] = b;
-            // the items of this frame become visible to the next launch through the list of item references
-            const int first = atomicAdd(&a.counters[0], n_items);
-            int *refs = reinterpret_cast<int *>(a.items + (size_t)gridDim.x * kPnpItemsPerFrame);
-            for (int i = 0; i < n_items; i++) refs[first + i] = b * kPnpItemsPerFrame + i;
-        }
-        return;
-    }
-    pnp_finish(S, obj, img, msk, n, fx, fy, cx, cy, thr2, inl, po, rto);
-}
-
-// second launch, part one: every work item (a run of up to PR_CHUNK hypotheses of one handed-over frame) solved and
-// scored by one block; blocks walk the item list with a grid stride
-__global__ __launch_bounds__(PR_THREADS) void k_pnp_more(PnpArgs a, int batch)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
-    float *obj, *img;
-    uint8_t *msk;
-    pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
-    const int tid = threadIdx.x;
-    const int n_work = a.counters[0];
-    const int *refs = reinterpret_cast<const int *>(a.items + (size_t)batch * kPnpItemsPerFrame);
-    const float thr2 = (float)(a.threshold * a.threshold);
-    for (int w = blockIdx.x; w < n_work; w += gridDim.x) {
-        const PnpItem it = a.items[refs[w]];
-        const int b = it.frame;
-        const int n = min(a.bp_info[b * 2 + 1], a.kp_stride);
-        __syncthreads();  // the previous item's points are no longer read
-        pnp_load_points(a.valid + (size_t)b * a.kp_stride, a.pts3 + (size_t)b * a.kp_stride * 3, n, obj, img, msk);
+        if (!share) break;
+        const int bb = pnp_claim(S, a);
+        if (bb < 0) break;
+        b = bb;
+        n = min(a.bp_info[b * 2 + 1], kp_stride);
+        const PnpItem it = a.items[(size_t)b * kPnpItemsPerFrame + S.claim_item];
+        const int n_items = S.claim_n;
+        __syncthreads();  // the previous frame's points and S.claim_* are no longer read
+        pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img, msk);
         if (tid == 0) S.pos = it.pos;
         __syncthreads();
         pnp_chain_round(S, n, a.rng_raw, a.rng_len, it.count);
-        pnp_solve_score(S, obj, img, n, PR_PER_WAVE, a.fx, a.fy, a.cx, a.cy, thr2);
-        const int nc = S.nchunk;  // == it.count: the same window, the same chain
-        PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax + it.first;
-        if (tid < nc) {
-            const int ok = S.ok[tid];
-            for (int i = 0; i < 6; i++) hy[tid].model[i] = ok ? S.model[tid][i] : 0.0;
-            hy[tid].count = ok ? S.counts[tid] : 0;
-            hy[tid].ok = ok ? 1 : 0;
+        pnp_solve_score(S, obj, img, n, PR_PER_WAVE, fx, fy, cx, cy, thr2);
+        {
+            const int nc = S.nchunk;  // == it.count: the same window, the same chain
+            PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax + it.first;
+            if (tid < nc) {
+                const int ok = S.ok[tid];
+                for (int i = 0; i < 6; i++) hy[tid].model[i] = ok ? S.model[tid][i] : 0.0;
+                hy[tid].count = ok ? S.counts[tid] : 0;
+                hy[tid].ok = ok ? 1 : 0;
+            }
+        }
+        __threadfence();  // the records before the completion count
+        __syncthreads();
+        if (tid == 0) {
+            S.last = atomicAdd(&a.done[b], 1) + 1 == n_items;
+            __threadfence();  // the other items' records (counted before this one) are read after this
+        }
+        __syncthreads();
+        if (S.last) {
+            // this was the frame's last item: its points are in LDS already
+            pnp_replay(S, a, b, n);
+            run = true;
         }
     }
 }
 
-// second launch, part two: one block per handed-over frame replays the acceptance rule over the stored hypotheses
-// in RNG order, runs whatever the sequential algorithm still asks for, and refines
-__global__ __launch_bounds__(PR_THREADS) void k_pnp_resume(PnpArgs a)
-{
-    if ((int)blockIdx.x >= a.counters[1]) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
-    float *obj, *img;
-    uint8_t *msk;
-    pnp_lds_views(s_dyn, a.kp_stride, obj, img, msk);
-    const int tid = threadIdx.x;
-    const int b = a.frames[blockIdx.x];
-    const int kp_stride = a.kp_stride;
-    const int n = min(a.bp_info[b * 2 + 1], kp_stride);
-    pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img, msk);
-    const float thr2 = (float)(a.threshold * a.threshold);
-    if (tid == 0) {
-        const PnpResume &r = a.resume[b];
-        for (int i = 0; i < 6; i++) S.best[i] = r.best[i];
-        S.pos = r.pos; S.iter = r.iter; S.niters = r.niters; S.max_good = r.max_good; S.done = 0;
-        const PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
-        for (int h = 0; h < r.n_spec; h++) {
-            if (hy[h].ok < 0) break;  // (never written: cannot happen while the item list is complete)
-            if (pnp_accept(S, hy[h].ok, hy[h].count, n, a.confidence))
-                for (int i = 0; i < 6; i++) S.best[i] = hy[h].model[i];
-            if (S.iter >= S.niters) { S.done = 1; break; }
-        }
-    }
-    __syncthreads();
-    // the stored hypotheses cover the iteration bound the frame left with, and the bound only shrinks: normally
-    // nothing is left; a shortened item list (RNG window ends, item capacity) continues here
-    if (!S.done) pnp_ransac_rounds(S, obj, img, n, a, thr2, false);
-    pnp_finish(S, obj, img, msk, n, a.fx, a.fy, a.cx, a.cy, thr2, a.inliers + (size_t)b * kp_stride, a.pose + b * 4,
-               a.rt + (size_t)b * 6);
-}
-
-size_t pnp_phase2_bytes(int batch, size_t off[5])
+size_t pnp_phase2_bytes(int batch, size_t off[4])
 {
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~size_t(255); return at; };
-    off[0] = take(2 * sizeof(int));                                                       // counters
-    off[1] = take((sizeof(PnpItem) + sizeof(int)) * (size_t)batch * kPnpItemsPerFrame);   // items, then item refs
-    off[2] = take(sizeof(int) * (size_t)batch);                                           // frames
-    off[3] = take(sizeof(PnpResume) * (size_t)batch);                                     // resume
-    off[4] = take(sizeof(PnpHyp) * (size_t)batch * kPnpSpecMax);                          // hyp
+    off[0] = take(3 * sizeof(int) * (size_t)batch);                                // state, next, done
+    off[1] = take(sizeof(PnpItem) * (size_t)batch * kPnpItemsPerFrame);            // items
+    off[2] = take(sizeof(PnpResume) * (size_t)batch);                              // resume
+    off[3] = take(sizeof(PnpHyp) * (size_t)batch * kPnpSpecMax);                   // hyp
     return o;
 }
 
@@ -2070,32 +2147,26 @@ void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_i
 {
     const size_t lds = ((sizeof(PrShared) + 15) & ~size_t(15)) + (size_t)kp_stride * (5 * sizeof(float) + 1) + 16;
     PnpArgs a{valid, pts3, bp_info, kp_stride, rng_raw, rng_len, fx, fy, cx, cy, max_iters, threshold, confidence,
-              inliers, pose, rt, nullptr, nullptr, nullptr, nullptr, nullptr};
-    // the second launch pays when hypotheses can outnumber two rounds; its buffers hold kPnpSpecMax per frame
-    const bool two = phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
-    if (two) {
-        size_t off[5];
+              inliers, pose, rt, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // handing frames over pays when hypotheses can outnumber two rounds
+    const bool share = phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
+    if (share) {
+        size_t off[4];
         (void)pnp_phase2_bytes(batch, off);
         unsigned char *p = static_cast<unsigned char *>(phase2);
-        a.counters = reinterpret_cast<int *>(p + off[0]);
+        a.state = reinterpret_cast<int *>(p + off[0]);
+        a.next = a.state + batch;
+        a.done = a.next + batch;
         a.items = reinterpret_cast<PnpItem *>(p + off[1]);
-        a.frames = reinterpret_cast<int *>(p + off[2]);
-        a.resume = reinterpret_cast<PnpResume *>(p + off[3]);
-        a.hyp = reinterpret_cast<PnpHyp *>(p + off[4]);
-        (void)hipMemsetAsync(a.counters, 0, 2 * sizeof(int), s);
+        a.resume = reinterpret_cast<PnpResume *>(p + off[2]);
+        a.hyp = reinterpret_cast<PnpHyp *>(p + off[3]);
+        (void)hipMemsetAsync(a.state, 0, 3 * sizeof(int) * (size_t)batch, s);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_ransac),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_pnp_ransac, dim3(batch), dim3(PR_THREADS), lds, s, a);
-    if (two) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_more),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_resume),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const int grid = min(1024, batch * kPnpItemsPerFrame);
-        hipLaunchKernelGGL(k_pnp_more, dim3(grid), dim3(PR_THREADS), lds, s, a, batch);
-        hipLaunchKernelGGL(k_pnp_resume, dim3(batch), dim3(PR_THREADS), lds, s, a);
-    }
+    hipLaunchKernelGGL(k_pnp_ransac, dim3(batch), dim3(PR_THREADS), lds, s, a, 0);
+    if (share)  // whatever was published after the last block of the first launch looked for work
+        hipLaunchKernelGGL(k_pnp_ransac, dim3(min(batch, 512)), dim3(PR_THREADS), lds, s, a, 1);
 }
 
 }  // namespace vo

@@ -161,7 +161,7 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMalloc(&d_rt, sizeof(double) * 6 * B));
     HIP_TRY(ctx, hipMalloc(&d_results, sizeof(vo_frame_result) * B));
     {
-        size_t off[5];
+        size_t off[4];
         HIP_TRY(ctx, hipMalloc(&d_pnp2, pnp_phase2_bytes(B, off)));
     }
     HIP_TRY(ctx, hipMemset(d_ages, 0, sizeof(int) * (size_t)kp_stride * slots));

@@ -216,13 +216,14 @@ void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_
 
 // cv::solvePnPRansac per frame on (pts3 -> prev 2-D point). pose = {success,
 // n_inliers, iters_run, n_points}; rt = rvec[3], tvec[3].
-// phase2: device scratch of pnp_phase2_bytes(batch) bytes for the frames that need many hypotheses (they are
-// spread over the chip by two follow-up launches); null keeps every frame in its own block.
+// phase2: device scratch of pnp_phase2_bytes(batch) bytes for the frames that need many hypotheses (their
+// hypotheses are spread over the blocks of the launch and of a follow-up launch); null keeps every frame in its
+// own block.
 void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_info, int kp_stride,
                        const uint32_t *rng_raw, int rng_len, double fx, double fy, double cx, double cy,
                        int max_iters, double threshold, double confidence, int *inliers, int *pose,
                        double *rt, int batch, void *phase2, hipStream_t s);
-size_t pnp_phase2_bytes(int batch, size_t off[5]);
+size_t pnp_phase2_bytes(int batch, size_t off[4]);
 
 // Copy the features and ages of each stream's last frame into its carry slot.
 void launch_carry(vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int kp_stride, int streams, int frames,
