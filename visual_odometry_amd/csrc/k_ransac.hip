@@ -15,6 +15,12 @@
 //      float32 compare, as OpenCV does);
 //   6. one lane replays the sequential "best so far" logic and the adaptive
 //      iteration bound.
+// Shortcuts that leave every result as it is: the collinearity test of step 2
+// runs only for the offsets the chain of step 3 actually visits; step 5
+// decides "error <= threshold" without the two divisions wherever the margin
+// allows and drops a candidate as soon as it cannot beat the best count of
+// the earlier rounds any more; step 6 finds the accepted candidates as a
+// prefix maximum over the round and walks only those.
 // fp64 expressions are evaluated in a fixed order with contraction disabled.
 #include <float.h>
 #include <math.h>
@@ -28,6 +34,7 @@ constexpr int FR_CHUNK = 64;
 constexpr int FR_FIRST = 8;  // iterations of the first round
 constexpr int FR_WIN = FR_CHUNK * 7 + 192;
 constexpr int FR_MAX_ATTEMPTS = 10000;
+constexpr int FR_VISIT = 2 * kWave;  // subset draws examined per round (usable or not), one lane each
 
 struct FrShared {
     double models[FR_CHUNK][3][9];
@@ -38,9 +45,13 @@ struct FrShared {
     int start[FR_CHUNK];
     uint16_t r[FR_WIN];
     uint8_t cons[FR_WIN];
-    uint8_t valid[FR_WIN];
     int wave_tot[FR_THREADS / kWave];
-    int nchunk;
+    int nchunk, nvisit, kend;
+    uint16_t visit[FR_VISIT];        // window offsets the chain visits; [nvisit] is where it goes on
+    uint16_t jump[2][FR_WIN + 2];    // offset reached from each window offset after 2^level subset draws
+    unsigned long long vmask[2];     // which of the visited offsets can be drawn from / hold a usable subset
+    double acc_ld[FR_CHUNK][3];      // log(1 - (1 - outlier ratio)^7) of the accepted candidates
+    unsigned long long acc_mask[3];  // accepted candidates of the round, per solution index
     int iter, niters, max_good, done, failed;
     int attempts;        // attempts already spent on the iteration being drawn
     long long pos;       // absolute index of the next unread RNG word
@@ -64,12 +75,12 @@ __device__ __forceinline__ bool collinear_last(const float (&m)[7][2])
 
 // draw one 7-subset starting at window offset o; returns draws consumed or 0
 // when the window ends first
-__device__ __forceinline__ int draw_subset(const uint16_t *r, int o, int (&idx)[7])
+__device__ __forceinline__ int draw_subset(const uint16_t *r, int o, int (&idx)[7], int win = FR_WIN)
 {
     int p = o;
     for (int i = 0; i < 7; i++) {
         for (;;) {
-            if (p >= FR_WIN) return 0;
+            if (p >= win) return 0;
             const int v = r[p++];
             bool dup = false;
             for (int j = 0; j < i; j++) dup = dup || (idx[j] == v);
@@ -266,16 +277,56 @@ __device__ __forceinline__ float f_error(const float4 p, const double *F)
     return (float)(e1 > e2 ? e1 : e2);
 }
 
-__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+// (float)max(e1, e2) <= thr of f_error() without its divisions: d^2 / q <= thr is decided as d^2 <= thr * q
+// with a relative margin of 1e-6 on either side (the float rounding of the error moves the threshold by 6e-8,
+// fp64 rounding by 1e-15); what falls inside the margin, and degenerate lines (q = 0, overflow, NaN), is left
+// undecided for the exact expression.  Returns 1 inlier, 0 outlier, -1 undecided.
+__device__ __forceinline__ int f_inlier_fast(const float4 p, const double *F, double thr_lo, double thr_hi)
+{
+    // (fused multiply-adds: this estimate need not round like f_error, the margin absorbs the difference)
+    const double x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
+    double a = fma(F[0], x1, fma(F[1], y1, F[2]));
+    double b = fma(F[3], x1, fma(F[4], y1, F[5]));
+    double c = fma(F[6], x1, fma(F[7], y1, F[8]));
+    const double q2 = fma(a, a, b * b);
+    const double d2 = fma(x2, a, fma(y2, b, c));
+    a = fma(F[0], x2, fma(F[3], y2, F[6]));
+    b = fma(F[1], x2, fma(F[4], y2, F[7]));
+    c = fma(F[2], x2, fma(F[5], y2, F[8]));
+    const double q1 = fma(a, a, b * b);
+    const double d1 = fma(x1, a, fma(y1, b, c));
+    const double dd1 = d1 * d1, dd2 = d2 * d2;
+    const bool sane = q1 > 0 && q2 > 0 && q1 + q2 < 1e300 && dd1 + dd2 < 1e300;
+    const bool in = dd1 <= thr_lo * q1 && dd2 <= thr_lo * q2;
+    const bool out = dd1 > thr_hi * q1 || dd2 > thr_hi * q2;
+    return !sane ? -1 : (in ? 1 : (out ? 0 : -1));
+}
+
+// cv::RANSACUpdateNumIters(p, ep, model_points, max_iters) in two steps, so that the expensive part (a power and
+// a logarithm per candidate) can be evaluated by many lanes at once and the cheap part replayed in sequence:
+//   ransac_log_outlier_term: log(1 - (1 - ep)^model_points), or +infinity where OpenCV returns 0 iterations;
+//   ransac_bound: the new bound from log(1 - p), that term and the current bound.
+__device__ __forceinline__ double ransac_log_confidence(double p)
 {
     p = p < 0 ? 0 : (p > 1 ? 1 : p);
+    const double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    return log(num);
+}
+__device__ __forceinline__ double ransac_log_outlier_term(double ep, int model_points)
+{
     ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
-    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
-    double denom = 1. - pow(1. - ep, (double)model_points);
-    if (denom < DBL_MIN) return 0;
-    num = log(num);
-    denom = log(denom);
-    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+    const double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return INFINITY;
+    return log(denom);
+}
+__device__ __forceinline__ int ransac_bound(double log_num, double log_denom, int max_iters)
+{
+    if (log_denom == INFINITY) return 0;
+    return log_denom >= 0 || -log_num >= max_iters * (-log_denom) ? max_iters : (int)rint(log_num / log_denom);
+}
+__device__ int ransac_update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    return ransac_bound(ransac_log_confidence(p), ransac_log_outlier_term(ep, model_points), max_iters);
 }
 
 #ifdef VO_FE_STAMPS
@@ -339,63 +390,125 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
     const float thr2 = (float)(prm.threshold * prm.threshold);
     FR_STAMP(1);
 
+    const double thr_lo = (double)thr2 * (1.0 - 1e-6), thr_hi = (double)thr2 * (1.0 + 1e-6);
     while (true) {
         FR_STAMP(2);
+        // The first round is short: on a typical frame pair the first model or two already explain most
+        // matches and the adaptive iteration count drops below it; later rounds take what is still needed.
+        const int want = min(S.iter == 0 && !lmeds ? FR_FIRST : FR_CHUNK, S.niters - S.iter);
+        const int base_good = S.max_good;  // best count of the earlier rounds
+        // the window holds the draws of `want` subsets plus room for repeated indices and rejected subsets
+        const int win = min(FR_WIN, want * 7 + 192);
         // 1. window of draws
         const long long pos = S.pos;
-        for (int k = tid; k < FR_WIN; k += FR_THREADS) {
+        for (int k = tid; k < win; k += FR_THREADS) {
             const long long a = pos + k;
             S.r[k] = a < rng_len ? (uint16_t)(rng_raw[a] % (uint32_t)n) : (uint16_t)0;
-            if (a >= rng_len) S.cons[k] = 0;
         }
         __syncthreads();
         FR_STAMP(3);
-        // 2. one subset attempt per window offset
-        for (int o = tid; o < FR_WIN; o += FR_THREADS) {
+        // 2. one subset draw per window offset: draws consumed (0: the window or the RNG table ends first)
+        for (int o = tid; o < win; o += FR_THREADS) {
             int idx[7];
-            int cons = draw_subset(S.r, o, idx);
+            int cons = draw_subset(S.r, o, idx, win);
             if (pos + o + cons > rng_len) cons = 0;
-            bool ok = false;
-            if (cons) {
-                float a[7][2], b[7][2];
-                for (int i = 0; i < 7; i++) {
-                    const float4 p = pts[idx[i]];
-                    a[i][0] = p.x; a[i][1] = p.y; b[i][0] = p.z; b[i][1] = p.w;
-                }
-                ok = !collinear_last(a) && !collinear_last(b);
-            }
             S.cons[o] = (uint8_t)cons;
-            S.valid[o] = (uint8_t)ok;
         }
         __syncthreads();
         FR_STAMP(4);
-        // 3. chain offsets into iterations
-        if (tid == 0) {
-            int w = 0, nc = 0, att = S.attempts;
-            // The first round is short: on a typical frame pair the first model or two already explain most
-            // matches and the adaptive iteration count drops below it; later rounds take what is still needed.
-            const int want = min(S.iter == 0 && !lmeds ? FR_FIRST : FR_CHUNK, S.niters - S.iter);
-            bool stuck = false;
-            while (nc < want && !stuck) {
-                for (;;) {
-                    if (w >= FR_WIN || S.cons[w] == 0) { stuck = true; break; }
-                    if (S.valid[w]) { S.start[nc++] = w; w += S.cons[w]; att = 0; break; }
-                    w += S.cons[w];
-                    if (++att >= FR_MAX_ATTEMPTS) { S.failed = 1; stuck = true; break; }
+        // 3. chain offsets into iterations.  Which offsets the chain visits does not depend on the subsets drawn
+        // there (a rejected subset consumes its draws like a usable one), only which of them count as iterations.
+        // The k-th visited offset is the k-fold image of offset 0 under o -> o + cons[o]: lane k composes it from
+        // the powers of two of that map (pointer doubling, seven levels), then tests the subset drawn there (OpenCV
+        // rejects one whose last point is collinear with two earlier ones) and takes its rank among the usable ones.
+        {
+            const int room = min(FR_VISIT - 1, want + 16);  // (more than 16 rejections shorten the round, nothing else)
+            for (int o = tid; o <= win; o += FR_THREADS) {
+                const int c = o < win ? S.cons[o] : 0;
+                S.jump[0][o] = (uint16_t)(c ? o + c : win);  // win: the chain cannot go on from here
+            }
+            __syncthreads();
+            int at = 0;
+#pragma unroll 1
+            for (int lv = 0; lv < 7; lv++) {
+                const uint16_t *J = S.jump[lv & 1];
+                uint16_t *Jn = S.jump[(lv + 1) & 1];
+                if (tid < FR_VISIT && ((tid >> lv) & 1)) at = J[at];
+                if (lv < 6)
+                    for (int o = tid; o <= win; o += FR_THREADS) Jn[o] = J[J[o]];
+                __syncthreads();
+            }
+            // (a stuck offset maps to `win`; landing on win exactly is the window's end: both stop the chain)
+            bool usable = false, drawable = false;
+            if (tid < FR_VISIT) {
+                drawable = tid < room && at < win && S.cons[at] != 0;
+                S.visit[tid] = (uint16_t)at;
+                const unsigned long long bm = __ballot(drawable);
+                if (lane == 0) S.vmask[wave] = bm;
+            }
+            __syncthreads();
+            // visited offsets: the drawable ones before the first that is not
+            const unsigned long long d0 = S.vmask[0], d1 = S.vmask[1];
+            const int nv = ~d0 ? __builtin_ctzll(~d0) : (~d1 ? 64 + __builtin_ctzll(~d1) : 128);
+            if (tid < FR_VISIT) {
+                if (tid < nv) {
+                    int idx[7];
+                    draw_subset(S.r, at, idx, win);
+                    float a[7][2], b[7][2];
+                    for (int i = 0; i < 7; i++) {
+                        const float4 p = pts[idx[i]];
+                        a[i][0] = p.x; a[i][1] = p.y; b[i][0] = p.z; b[i][1] = p.w;
+                    }
+                    usable = !collinear_last(a) && !collinear_last(b);
                 }
             }
-            S.nchunk = nc;
-            S.attempts = att;
-            S.pos = pos + w;
-            if (nc == 0 && w == 0) S.failed = 1;  // RNG table exhausted: cannot progress
+            __syncthreads();  // (everybody has read the drawable masks)
+            if (tid < FR_VISIT) {
+                const unsigned long long bm = __ballot(usable);
+                if (lane == 0) S.vmask[wave] = bm;
+            }
+            if (tid == 0) S.kend = nv;
+            __syncthreads();
+            const unsigned long long u0 = S.vmask[0], u1 = S.vmask[1];
+            const int total = __popcll(u0) + __popcll(u1);
+            if (tid < FR_VISIT && usable) {
+                const int rank = tid < 64 ? __popcll(u0 & ((1ull << lane) - 1ull))
+                                          : __popcll(u0) + __popcll(u1 & ((1ull << lane) - 1ull));
+                if (rank < want) S.start[rank] = (uint16_t)at;
+                if (rank == want - 1) S.kend = tid + 1;  // the round ends behind the want-th usable subset
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int kend = S.kend;  // visited offsets this round consumes
+                // attempts pending = rejected subsets since the last usable one
+                const unsigned long long m0 = kend >= 64 ? u0 : (u0 & ((1ull << kend) - 1ull));
+                const unsigned long long m1 = kend >= 128 ? u1 : (kend > 64 ? (u1 & ((1ull << (kend - 64)) - 1ull)) : 0ull);
+                int att;
+                if (m1) att = kend - 1 - (127 - __builtin_clzll(m1));
+                else if (m0) att = kend - 1 - (63 - __builtin_clzll(m0));
+                else att = S.attempts + kend;
+                int nc = min(total, want);
+                // cv's getSubset gives up after FR_MAX_ATTEMPTS rejections in a row: only reachable with rejections
+                // carried over from earlier rounds, before the first usable subset of this one
+                const int first = m0 ? __builtin_ctzll(m0) : (m1 ? 64 + __builtin_ctzll(m1) : kend);
+                if (S.attempts + first >= FR_MAX_ATTEMPTS) {
+                    S.failed = 1;
+                    nc = 0;
+                    att = FR_MAX_ATTEMPTS;
+                }
+                S.nchunk = nc;
+                S.attempts = att;
+                S.pos = pos + S.visit[kend];
+                if (nv == 0) S.failed = 1;  // RNG table exhausted: cannot progress
+            }
+            __syncthreads();
         }
-        __syncthreads();
         FR_STAMP(5);
         const int nc = S.nchunk;
         // 4. solve
         if (tid < nc) {
             int idx[7];
-            draw_subset(S.r, S.start[tid], idx);
+            draw_subset(S.r, S.start[tid], idx, win);
             float a[7][2], b[7][2];
             for (int i = 0; i < 7; i++) {
                 const float4 p = pts[idx[i]];
@@ -422,38 +535,108 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
                 if (lane < n && rank == n / 2) S.counts[h][m] = __float_as_int(e);
                 continue;
             }
+            // a candidate is accepted only with more inliers than max(best so far, 6): once the points left
+            // cannot lift it above the best of the earlier rounds its count no longer matters
+            const int need = max(base_good, 6);
             int cnt = 0;
-            for (int i = lane; i < n; i += kWave) cnt += (f_error(pts[i], F) <= thr2);
-            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            // four points per lane and step, so that the loads and the arithmetic of one hide the latencies of another
+            for (int i0 = 0; i0 < n; i0 += 4 * kWave) {
+                int in[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * kWave + lane;
+                    const int r = f_inlier_fast(pts[min(i, n - 1)], F, thr_lo, thr_hi);
+                    in[u] = i < n ? r : 0;
+                }
+                if (__any((in[0] | in[1] | in[2] | in[3]) < 0)) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (in[u] < 0) in[u] = f_error(pts[i0 + u * kWave + lane], F) <= thr2;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) cnt += __popcll(__ballot(in[u] > 0));
+                if (cnt + max(n - i0 - 4 * kWave, 0) <= need) break;
+            }
             if (lane == 0) S.counts[h][m] = cnt;
         }
         __syncthreads();
         FR_STAMP(7);
         // 6. sequential acceptance
-        if (tid == 0) {
-            for (int h = 0; h < nc; h++) {
-                const int nm = S.nmodels[h];
-                for (int m = 0; m < nm; m++) {
-                    if (lmeds) {
+        if (lmeds) {
+            if (tid == 0) {
+                for (int h = 0; h < nc; h++) {
+                    const int nm = S.nmodels[h];
+                    for (int m = 0; m < nm; m++) {
                         const double median = (double)__int_as_float(S.counts[h][m]);
                         if (median < S.min_median) {
                             S.min_median = median;
                             for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
                         }
-                        continue;
                     }
-                    const int goodc = S.counts[h][m];
-                    if (goodc > max(S.max_good, 6)) {
-                        for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
-                        S.max_good = goodc;
-                        S.niters = ransac_update_num_iters(prm.confidence, (double)(n - goodc) / n, 7, S.niters);
-                    }
+                    S.iter++;
+                    if (S.iter >= S.niters) break;
                 }
-                S.iter++;
-                if (S.iter >= S.niters) break;
+                if (S.iter >= S.niters) S.done = 1;
+                if (S.failed) S.done = 1;
             }
-            if (S.iter >= S.niters) S.done = 1;
-            if (S.failed) S.done = 1;  // getSubset gave up: stop (iter == 0 -> nothing found)
+        } else if (wave == 0) {
+            // candidate (h, m) is accepted when its count beats max(best so far, 6) and every earlier candidate of
+            // the round: lane h holds the counts of iteration h, a prefix maximum over the lanes finds the accepted
+            // ones, lane 0 walks them in order, moves the iteration bound and finds where the loop stops
+            int c[3];
+            const int nm = lane < nc ? S.nmodels[lane] : 0;
+#pragma unroll
+            for (int m = 0; m < 3; m++) c[m] = m < nm ? S.counts[lane][m] : -1;
+            const int mine = max(c[0], max(c[1], c[2]));
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(incl, off);
+                if (lane >= off) incl = max(incl, y);
+            }
+            int run = __shfl_up(incl, 1);
+            if (lane == 0) run = -1;
+            run = max(run, max(base_good, 6));
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const bool acc = c[m] > run;
+                run = max(run, c[m]);
+                const unsigned long long bm = __ballot(acc);
+                if (lane == 0) S.acc_mask[m] = bm;
+                // the costly half of the new iteration bound, for every accepted candidate at once
+                if (acc) S.acc_ld[lane][m] = ransac_log_outlier_term((double)(n - c[m]) / n, 7);
+            }
+            if (lane == 0) {
+                const double log_conf = ransac_log_confidence(prm.confidence);
+                unsigned long long any = S.acc_mask[0] | S.acc_mask[1] | S.acc_mask[2];
+                const int it0 = S.iter;
+                int N = S.niters, prev = 0, final_iter = it0 + nc;
+                bool stop = false;
+                // between two accepted candidates the bound N is constant: the loop stops at the first iteration
+                // j of the stretch with it0 + j + 1 >= N
+                while (any) {
+                    const int h = __builtin_ctzll(any);
+                    any &= any - 1;
+                    const int j = max(prev, N - it0 - 1);
+                    if (j <= h - 1) { stop = true; final_iter = it0 + j + 1; break; }
+                    for (int m = 0; m < 3; m++)
+                        if ((S.acc_mask[m] >> h) & 1ull) {
+                            const int goodc = S.counts[h][m];
+                            for (int i = 0; i < 9; i++) S.best[i] = S.models[h][m][i];
+                            S.max_good = goodc;
+                            N = ransac_bound(log_conf, S.acc_ld[h][m], N);
+                        }
+                    prev = h;
+                }
+                if (!stop) {
+                    const int j = max(prev, N - it0 - 1);
+                    if (j <= nc - 1) final_iter = it0 + j + 1;
+                }
+                S.iter = final_iter;
+                S.niters = N;
+                if (S.iter >= S.niters) S.done = 1;
+                if (S.failed) S.done = 1;  // getSubset gave up: stop (iter == 0 -> nothing found)
+            }
         }
         __syncthreads();
         FR_STAMP(8);
