@@ -41,6 +41,18 @@ static bool is_device_ptr(const void *p)
     return a.type == hipMemoryTypeDevice;
 }
 
+// host memory the GPU can read by DMA without a staging pass (hipHostMalloc / hipHostRegister): copies from it
+// return at once, copies from ordinary memory occupy the calling thread until the data has left it
+static bool is_pinned_host_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 int vo_ctx::ensure_essential(int n_points, int n_hyp)
 {
     vo_ctx *c = this;
@@ -306,23 +318,127 @@ static int ensure_pack(vo_ctx *c, int B)
 // area.  Packed input goes up as ONE linear copy, planes with packed rows as one copy each; only padded rows
 // take the 2-D path (which the runtime executes row by row: 13 ms for one HD720 BGRA + depth pair against
 // 1 ms for the two linear copies).
+// With `stage` (pinned memory of count * rows * row_bytes bytes) the planes are first packed into it piece by piece,
+// each piece's DMA starting while the next piece is being packed: for ordinary (pageable) memory the runtime's own
+// staging alternates between the two (1 MB packed, 1 MB sent, ...: 145 us for an HD720 BGRA frame, 115 us this way).
 static int upload_planes(vo_ctx *c, uint8_t *dst, const uint8_t *src, size_t row_bytes, int rows, size_t row_stride,
-                         size_t plane_stride, int count)
+                         size_t plane_stride, int count, hipStream_t stream, uint8_t *stage = nullptr)
 {
     const size_t plane_bytes = row_bytes * (size_t)rows;
+    if (stage) {
+        const size_t total = plane_bytes * (size_t)count;
+        size_t done = 0, piece = 256u << 10;  // small pieces first, so that the link starts early
+        while (done < total) {
+            const size_t len = std::min(piece, total - done);
+            if (row_stride == row_bytes && (count == 1 || plane_stride == plane_bytes)) {
+                memcpy(stage + done, src + done, len);
+            } else {
+                size_t o = done;
+                while (o < done + len) {  // row by row out of the padded source
+                    const size_t pl = o / plane_bytes, in_plane = o - pl * plane_bytes;
+                    const size_t row = in_plane / row_bytes, col = in_plane - row * row_bytes;
+                    const size_t n = std::min(row_bytes - col, done + len - o);
+                    memcpy(stage + o, src + pl * plane_stride + row * row_stride + col, n);
+                    o += n;
+                }
+            }
+            HIP_TRY(c, hipMemcpyAsync(dst + done, stage + done, len, hipMemcpyHostToDevice, stream));
+            done += len;
+            if (piece < (1u << 20)) piece *= 2;
+        }
+        return VO_OK;
+    }
     if (row_stride == row_bytes && (count == 1 || plane_stride == plane_bytes)) {
-        HIP_TRY(c, hipMemcpyAsync(dst, src, plane_bytes * count, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst, src, plane_bytes * count, hipMemcpyHostToDevice, stream));
         return VO_OK;
     }
     for (int i = 0; i < count; i++) {
         if (row_stride == row_bytes)
             HIP_TRY(c, hipMemcpyAsync(dst + i * plane_bytes, src + i * plane_stride, plane_bytes, hipMemcpyHostToDevice,
-                                      c->stream));
+                                      stream));
         else
             HIP_TRY(c, hipMemcpy2DAsync(dst + i * plane_bytes, row_bytes, src + i * plane_stride, row_stride, row_bytes,
-                                        rows, hipMemcpyHostToDevice, c->stream));
+                                        rows, hipMemcpyHostToDevice, stream));
     }
     return VO_OK;
+}
+
+// Pack count planes of rows x row_bytes bytes (rows row_stride, planes plane_stride bytes apart) into dst.
+static void pack_planes(uint8_t *dst, const uint8_t *src, size_t row_bytes, int rows, size_t row_stride,
+                        size_t plane_stride, int count)
+{
+    const size_t plane_bytes = row_bytes * (size_t)rows;
+    if (row_stride == row_bytes && (count == 1 || plane_stride == plane_bytes)) {
+        memcpy(dst, src, plane_bytes * (size_t)count);
+        return;
+    }
+    for (int i = 0; i < count; i++)
+        for (int r = 0; r < rows; r++)
+            memcpy(dst + i * plane_bytes + (size_t)r * row_bytes, src + i * plane_stride + (size_t)r * row_stride,
+                   row_bytes);
+}
+
+void vo_ctx::stager_loop()
+{
+    (void)hipSetDevice(device);
+    DepthStager &w = stager;
+    std::unique_lock<std::mutex> lk(w.m);
+    for (;;) {
+        w.cv.wait(lk, [&] { return w.posted || w.quit; });
+        if (w.quit) return;
+        w.posted = false;
+        lk.unlock();
+        pack_planes(w.stage, w.src, w.row_bytes, w.rows, w.row_stride, w.plane_stride, w.count);
+        lk.lock();
+        w.cv.wait(lk, [&] { return w.go || w.quit; });
+        if (w.quit) return;
+        w.go = false;
+        hipError_t e = hipSuccess;
+        if (!w.cancel) {
+            lk.unlock();
+            // behind the frames' copy: two copies at once would share the link and delay the frames
+            if (w.wait_frames) e = hipStreamWaitEvent(copy_stream, ev_frames, 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(w.dst, w.stage, w.row_bytes * (size_t)w.rows * w.count, hipMemcpyHostToDevice,
+                                   copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(ev_depth, copy_stream);
+            lk.lock();
+        }
+        w.err = (int)e;
+        w.issued = true;
+        w.cv.notify_all();
+    }
+}
+
+void vo_ctx::stager_stop()
+{
+    if (!stager.th.joinable()) return;
+    {
+        std::lock_guard<std::mutex> g(stager.m);
+        stager.quit = true;
+    }
+    stager.cv.notify_all();
+    stager.th.join();
+}
+
+// Pinned staging for batches that come from ordinary host memory: room for the frames (twice with a right image)
+// and the depth planes of one batch, only while that is small (the single-stream path; a large host-fed batch
+// should come from pinned memory in the first place).
+static uint8_t *stage_area(vo_ctx *c, size_t bytes)
+{
+    if (bytes > vo_ctx::kStageMaxBytes) return nullptr;
+    if (bytes > c->h_stage_bytes) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_bytes = 0;
+        if (hipHostMalloc(&c->h_stage, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_stage = nullptr;
+            return nullptr;
+        }
+        c->h_stage_bytes = bytes;
+    }
+    return static_cast<uint8_t *>(c->h_stage);
 }
 
 // vo_batch_submit and vo_batch_submit_stereo: with `right` (and `st`) the depth planes come from the stereo
@@ -367,30 +483,118 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const size_t frame_stride_in = frame_stride;
     const bool right_on_host = right && !is_device_ptr(right);
     const uint8_t *src = frames;
-    if (!is_device_ptr(frames)) {
-        int rc0 = upload_planes(c, c->d_in, frames, row_bytes, b.height, row_stride, frame_stride, B);
+    const size_t frames_bytes = (size_t)row_bytes * b.height * B;
+    const size_t depth_bytes = sizeof(float) * (size_t)b.width * b.height * B;
+    const bool frames_host = !is_device_ptr(frames);
+    const bool depth_host_mem = depth && b.enable_pose && !right && !is_device_ptr(depth);
+    // ordinary (not pinned) host memory goes through the context's own pinned staging area
+    const bool stage_frames = frames_host && !is_pinned_host_ptr(frames);
+    const bool stage_right = right_on_host && !is_pinned_host_ptr(right);
+    const bool stage_depth = depth_host_mem && !is_pinned_host_ptr(depth);
+    uint8_t *stage = nullptr;
+    // VO_STAGE=0: leave ordinary host memory to the runtime's staging (for comparisons)
+    static const bool own_stage = !(getenv("VO_STAGE") && getenv("VO_STAGE")[0] == '0');
+    if (own_stage && (stage_frames || stage_right || stage_depth))
+        stage = stage_area(c, 2 * frames_bytes + depth_bytes);  // (null: too large, the runtime stages)
+    // a depth plane in ordinary memory is packed by the helper thread from now on, beside the work of this one
+    const bool depth_by_helper = stage_depth && stage != nullptr;
+    struct StagerGuard {  // whatever happens below, a posted job is brought to its end before this call returns
+        vo_ctx::DepthStager *w = nullptr;
+        bool released = false;
+        void release(bool cancel)
+        {
+            if (!w || released) return;
+            released = true;
+            {
+                std::lock_guard<std::mutex> g(w->m);
+                w->cancel = cancel;
+                w->go = true;
+            }
+            w->cv.notify_all();
+        }
+        int finish()  // waits until the helper has queued (or dropped) the copy; its HIP status
+        {
+            if (!w) return 0;
+            release(true);
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->issued; });
+            w->issued = false;
+            vo_ctx::DepthStager *done = w;
+            w = nullptr;
+            return done->err;
+        }
+        ~StagerGuard() { (void)finish(); }
+    } helper;
+    if (depth_by_helper) {
+        vo_ctx::DepthStager &w = c->stager;
+        if (!w.th.joinable()) w.th = std::thread([c] { c->stager_loop(); });
+        {
+            std::lock_guard<std::mutex> g(w.m);
+            w.src = reinterpret_cast<const uint8_t *>(depth);
+            w.stage = stage + 2 * frames_bytes;
+            w.dst = reinterpret_cast<uint8_t *>(c->d_depth);
+            w.row_bytes = sizeof(float) * b.width; w.rows = b.height;
+            w.row_stride = sizeof(float) * (size_t)depth_row_stride;
+            w.plane_stride = sizeof(float) * depth_frame_stride;
+            w.count = B;
+            w.wait_frames = frames_host;
+            w.posted = true; w.go = false; w.cancel = false; w.issued = false; w.err = 0;
+        }
+        w.cv.notify_all();
+        helper.w = &w;
+    }
+    if (frames_host) {
+        int rc0 = upload_planes(c, c->d_in, frames, row_bytes, b.height, row_stride, frame_stride, B, c->stream,
+                                stage_frames ? stage : nullptr);
         if (rc0) return rc0;
         src = c->d_in;
         row_stride = row_bytes;
         frame_stride = (size_t)row_bytes * b.height;
     }
+    // (the helper queues the depth copy behind the frames' copies; it is told to once nothing records a graph any more)
+    if (depth_by_helper && frames_host) HIP_TRY(c, hipEventRecord(c->ev_frames, c->stream));
     const uint8_t *rsrc = right;
     if (right_on_host) {
-        uint8_t *stage = c->d_in + (size_t)B * row_bytes * b.height;  // second half of the staging area
-        int rc0 = upload_planes(c, stage, right, row_bytes, b.height, row_stride_in, frame_stride_in, B);
+        uint8_t *dst = c->d_in + frames_bytes;  // second half of the staging area on the device
+        int rc0 = upload_planes(c, dst, right, row_bytes, b.height, row_stride_in, frame_stride_in, B, c->stream,
+                                stage_right && stage ? stage + frames_bytes : nullptr);
         if (rc0) return rc0;
-        rsrc = stage;
+        rsrc = dst;
     }
     const float *dsrc = depth;
-    if (depth && b.enable_pose && !is_device_ptr(depth)) {
+    // A depth plane in host memory is not needed before the back-projection stage: it goes up on a second stream
+    // while detection and matching of the frame already run (half of the bytes of a BGRA + float32-depth frame)
+    const bool depth_from_host = depth_host_mem;
+    const float *depth_host = depth;
+    const int depth_row_stride_host = depth_row_stride;
+    const size_t depth_frame_stride_host = depth_frame_stride;
+    if (depth_from_host) {
         c->depth_planes_nan = false;
-        int rc0 = upload_planes(c, reinterpret_cast<uint8_t *>(c->d_depth), reinterpret_cast<const uint8_t *>(depth),
-                                sizeof(float) * b.width, b.height, sizeof(float) * depth_row_stride,
-                                sizeof(float) * depth_frame_stride, B);
-        if (rc0) return rc0;
         dsrc = c->d_depth;
         depth_row_stride = b.width;
         depth_frame_stride = (size_t)b.width * b.height;
+    }
+    const bool frames_from_host = src != frames;
+    // Pinned depth: the copy is queued before any kernel is launched, behind the frames' copy (two copies at once
+    // would share the link and delay the frames, which everything waits for).  Ordinary memory: the copy call
+    // keeps this thread busy, so it is made after the first part of the chain has been launched.
+    const bool depth_early = depth_from_host && !stage_depth;
+    const bool depth_late = depth_from_host && !depth_early && !depth_by_helper;
+    auto upload_depth = [&]() -> int {
+        if (frames_from_host) {
+            HIP_TRY(c, hipEventRecord(c->ev_frames, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_frames, 0));
+        }
+        int rc0 = upload_planes(c, reinterpret_cast<uint8_t *>(c->d_depth), reinterpret_cast<const uint8_t *>(depth_host),
+                                sizeof(float) * b.width, b.height, sizeof(float) * depth_row_stride_host,
+                                sizeof(float) * depth_frame_stride_host, B, c->copy_stream);
+        if (rc0) return rc0;
+        HIP_TRY(c, hipEventRecord(c->ev_depth, c->copy_stream));
+        return VO_OK;
+    };
+    if (depth_early) {
+        int rc0 = upload_depth();
+        if (rc0) return rc0;
     }
     if (!b.enable_pose) dsrc = nullptr;
     const int r_slot0 = S + B;  // feature slots of the right images
@@ -416,7 +620,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const int rs = right_on_host ? row_bytes : row_stride_in;
     const size_t fs = right_on_host ? (size_t)row_bytes * b.height : frame_stride_in;
 
-    auto chain = [&]() {
+    // the kernel chain in two parts: everything that needs the frames only, then everything from the depth plane on
+    auto chain_front = [&]() {
         if (c->packed) launch_stamp(c->d_stamps, c->stream);
         if (right) {
             // the right images first, without timing marks: the marks of the detector stages are the left images'
@@ -450,6 +655,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
                           c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
         c->mark(9);
+    };
+    auto chain_back = [&]() {
         launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
                                   c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
                                   depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
@@ -496,27 +703,46 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         if (c->graph_exec && !(key == c->graph_key)) c->drop_graph();
         key.generation = c->generation;
         if (!c->graph_exec) {
-            hipGraph_t graph = nullptr;
-            HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-            c->capturing = true;
-            chain();
-            c->capturing = false;
-            hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-            if (ce != hipSuccess || !graph) {
-                (void)hipGetLastError();
-                return bfail(c, VO_ERR_HIP, "vo_batch_submit: graph capture failed: %s", hipGetErrorString(ce));
-            }
-            ce = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ce != hipSuccess) {
-                c->graph_exec = nullptr;
-                return bfail(c, VO_ERR_HIP, "vo_batch_submit: hipGraphInstantiate: %s", hipGetErrorString(ce));
+            // two recordings, so that the wait for the depth plane sits between them
+            for (int part = 0; part < 2; part++) {
+                hipGraph_t graph = nullptr;
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+                c->capturing = true;
+                if (part == 0) chain_front(); else chain_back();
+                c->capturing = false;
+                hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+                if (ce != hipSuccess || !graph) {
+                    (void)hipGetLastError();
+                    c->drop_graph();
+                    return bfail(c, VO_ERR_HIP, "vo_batch_submit: graph capture failed: %s", hipGetErrorString(ce));
+                }
+                hipGraphExec_t *slot = part == 0 ? &c->graph_exec : &c->graph_exec_back;
+                ce = hipGraphInstantiate(slot, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) {
+                    *slot = nullptr;
+                    c->drop_graph();
+                    return bfail(c, VO_ERR_HIP, "vo_batch_submit: hipGraphInstantiate: %s", hipGetErrorString(ce));
+                }
             }
             c->graph_key = key;
         }
+        helper.release(false);
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
     } else {
-        chain();
+        helper.release(false);
+        chain_front();
+    }
+    if (depth_late && (rc = upload_depth())) return rc;
+    if (depth_by_helper) {
+        const hipError_t he = (hipError_t)helper.finish();
+        if (he != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: depth upload: %s", hipGetErrorString(he));
+    }
+    if (depth_from_host) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_depth, 0));
+    if (c->use_graph) {
+        HIP_TRY(c, hipGraphLaunch(c->graph_exec_back, c->stream));
+    } else {
+        chain_back();
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: %s", hipGetErrorString(e));

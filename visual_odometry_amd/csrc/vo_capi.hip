@@ -117,6 +117,9 @@ int vo_ctx::allocate()
     vo_ctx *ctx = this;
     HIP_TRY(ctx, hipSetDevice(device));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_depth, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ev_frames, hipEventDisableTiming));
     const int B = cfg.max_batch;
     pitch = align_up(cfg.max_width, 128);
     hpad = align_up(cfg.max_height, 16);
@@ -203,6 +206,7 @@ int vo_ctx::allocate()
 
 void vo_ctx::release()
 {
+    stager_stop();
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_flat, d_cand_count, d_orb_cand_flat, d_kps, d_desc, d_nkp, d_pattern,
                     d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0, d_orb_tab, d_eq, d_eE, d_eidx, d_enm, d_ecnt, d_einfo, d_emask,
                     d_st_idx, d_st_disp, d_st_depth, d_st_plane, d_st_n,
@@ -218,6 +222,10 @@ void vo_ctx::release()
     if (d_stamps) (void)hipFree(d_stamps);
     if (h_pack) (void)hipHostFree(h_pack);
     if (h_pinned) (void)hipHostFree(h_pinned);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (ev_depth) (void)hipEventDestroy(ev_depth);
+    if (ev_frames) (void)hipEventDestroy(ev_frames);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -1,13 +1,19 @@
 // Device-side state of one vo_ctx.
 #pragma once
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "vo_internal.h"
 
 struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // uploads that overlap the kernels on `stream` (depth planes from the host)
+    hipEvent_t ev_depth = nullptr;      // the depth planes of the batch are on the device
+    hipEvent_t ev_frames = nullptr;     // the frames of the batch are on the device
     vo_cfg cfg{};
     vo::GrayCoeffs gc{};
     std::string err;
@@ -104,7 +110,8 @@ struct vo_ctx {
     unsigned long long *d_stamps = nullptr;
     double wall_clock_khz = 0;
     bool use_graph = false;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraphExec_t graph_exec = nullptr;       // detection, matching, track ages
+    hipGraphExec_t graph_exec_back = nullptr;  // back-projection, pose, outputs (waits for the depth upload)
     // what the captured graph was built for.  `generation` counts every event that invalidates a recorded chain
     // without showing in the other fields: a new batch configuration or camera, a re-planned pyramid, reallocated
     // buffers.  Compared field by field (struct padding is never looked at).
@@ -133,7 +140,8 @@ struct vo_ctx {
     void drop_graph()
     {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        graph_exec = nullptr;
+        if (graph_exec_back) (void)hipGraphExecDestroy(graph_exec_back);
+        graph_exec = graph_exec_back = nullptr;
         generation++;
     }
 
@@ -146,6 +154,29 @@ struct vo_ctx {
     {
         if (timing && marks_on && !capturing) (void)hipEventRecord(ev[i], stream);
     }
+
+    // pinned staging for frames and depth planes handed over in ordinary host memory (small batches only)
+    static constexpr size_t kStageMaxBytes = 64u << 20;
+    void *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+
+    // Helper thread of the single-stream path: packs a depth plane that arrives in ordinary host memory into the
+    // pinned staging area while the caller's thread stages the frame and launches the first kernels, then queues
+    // its DMA behind the frame's.  Started on first use.
+    struct DepthStager {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        bool posted = false, go = false, cancel = false, issued = false, quit = false;
+        const uint8_t *src = nullptr;
+        uint8_t *stage = nullptr, *dst = nullptr;
+        size_t row_bytes = 0, row_stride = 0, plane_stride = 0;
+        int rows = 0, count = 0;
+        bool wait_frames = false;
+        int err = 0;  // hipError_t of the worker's calls
+    } stager;
+    void stager_loop();
+    void stager_stop();
 
     static constexpr size_t kPinnedBytes = 1 << 20;
     size_t pinned_bytes = 0;  // max(kPinnedBytes, max_batch result records)
