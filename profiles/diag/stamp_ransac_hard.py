@@ -59,13 +59,21 @@ def main():
         pn = np.zeros((256, 16), np.uint64)
         raw.vo_debug_pnp_stamps.argtypes = [C.c_void_p]
         assert raw.vo_debug_pnp_stamps(pn.ctypes.data) == 0
-        t = pn[:, :11].astype(np.int64)
+        t = pn[:, :15].astype(np.int64)
+        # stamps: 0 start, 1 points loaded, 2 subsets chained (last round), 3 hypotheses solved, 4 scored + accepted,
+        # 5 inlier list, 6 planarity, 7 DLT sums, 8 null vector, 9 initial pose, 10 Levenberg-Marquardt done;
+        # inside the solver (last round): 11 start, 12 control points, 13 singular vectors, 14 betas + pose
+        names = ["load points", "rng window + chain (last round)", "solve hypotheses (last round)",
+                 "score + accept (last round)", "inlier mask + list", "planarity", "DLT sums", "null vector",
+                 "polar + Rodrigues", "Levenberg-Marquardt"]
+        for i, nme in enumerate(names):
+            dlt = t[:, i + 1] - t[:, i]
+            print(f"PnP {nme:36s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
+        for i, nme in enumerate(["solver: control points", "solver: singular vectors", "solver: betas + pose"]):
+            dlt = t[:, 12 + i] - t[:, 11 + i]
+            print(f"PnP   {nme:34s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
         tot = t[:, 10] - t[:, 0]
-        loop = t[:, 4] - t[:, 1]
-        print("PnP blocks 0..255: whole kernel cycles median %d p90 %d max %d; RANSAC loop median %d max %d; "
-              "after the loop median %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(loop),
-                                                   loop.max(), np.median(t[:, 10] - t[:, 4]), (t[:, 10] - t[:, 4]).max()))
-        print("PnP kernel first start -> last end (blocks 0..255):", int(t[:, 10].max() - t[:, 0].min()))
+        print("PnP whole block: median %d p90 %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max()))
         fr = np.zeros((256, 16), np.uint64)
         raw.vo_debug_fr_stamps.argtypes = [C.c_void_p]
         assert raw.vo_debug_fr_stamps(fr.ctypes.data) == 0

@@ -62,3 +62,41 @@ def test_hard_scene_streams_match_oracle(oracle, scene):
             assert np.mean(outl) > 0.2 and np.mean(iters) > 20
     finally:
         c.close()
+
+
+@pytest.mark.timeout(300)
+def test_pnp_hand_over_large_batch_equals_small_batches():
+    """Frames that need many PnP hypotheses publish them as work items.  In a large launch the blocks that have
+    finished their own frame claim the items; in a small one a second launch does.  Both must give what the
+    small batches give (which the test above compares with the oracle): the same iteration counts, inlier lists
+    and poses, bit for bit."""
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F, N = 32, 4, 1000
+    frames, depth, _ = synth.make_pingpong_batch(cam, S, F, seed=53000, channels=4, relief=2.0, movers=30, workers=4)
+
+    def run(streams, lo):
+        c = capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=N + 64,
+                         max_batch=streams * F)
+        try:
+            c.batch_configure(cam.width, cam.height, 4, n_streams=streams, frames_per_stream=F, max_features=N,
+                              fast_threshold=20, camera=K, orb_levels=8)
+            sl = slice(lo * F, (lo + streams) * F)
+            c.batch_submit(frames[sl], depth[sl])
+            res = c.batch_wait()
+            inl = [c.batch_inliers(b) for b in range(streams * F)]
+            return res, inl
+        finally:
+            c.close()
+
+    big, big_inl = run(S, 0)                      # 128 frames: shared among the blocks of one launch
+    assert (big["pnp_iters"] > 18).sum() >= 3, "the scene must contain frames that are handed over"
+    for lo in range(0, S, 8):                     # 32 frames at a time: the two-launch path
+        small, small_inl = run(8, lo)
+        for b in range(8 * F):
+            g = lo * F + b
+            for name in ("pnp_success", "pnp_inliers", "pnp_iters", "pnp_points", "n_3d"):
+                assert big[name][g] == small[name][b], (g, name)
+            assert np.array_equal(big["rvec"][g], small["rvec"][b]) and np.array_equal(big["tvec"][g], small["tvec"][b])
+            assert np.array_equal(big_inl[g], small_inl[b])

@@ -886,8 +886,10 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(const uint8_t *__restri
                                                          GrayCoeffs c, uint32_t *__restrict__ cand,
                                                          uint32_t *__restrict__ tile_count, int batch,
                                                          uint32_t inv_tiles_x, int margin, uint32_t inv_tiles_y,
-                                                         int by_rows)
+                                                         int by_rows, unsigned long long *stamp)
 {
+    // (optional: the device wall clock at the start of the launch, for callers that time the detector)
+    if (stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *stamp = wall_clock64();
     if (!by_rows) {
         fe_tile<CN>(src, width, height, src_stride, src_frame_stride, gray_out, score, blur, thr, c, cand, tile_count,
                     batch, inv_tiles_x, margin, (int)(blockIdx.y * 8 + (blockIdx.x & 7)), (int)(blockIdx.x >> 3));
@@ -967,7 +969,8 @@ static bool tile_order_by_rows()
 
 void launch_frontend(const uint8_t *src, int width, int height, int src_stride, size_t src_frame_stride,
                      int channels, PlaneBatch gray_out, PlaneBatch score, PlaneBatch blur, int threshold,
-                     uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s, int margin)
+                     uint32_t *cand, uint32_t *tile_count, int batch, GrayCoeffs c, hipStream_t s, int margin,
+                     unsigned long long *stamp)
 {
     // block b serves XCD group b % 8, which owns the tile columns congruent to
     // b % 8; the grid holds the largest group's tile count for every group
@@ -981,15 +984,15 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride, 
     if (channels == 1)
         hipLaunchKernelGGL(k_frontend<1>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y, by_rows ? 1 : 0);
+                           inv_tiles_y, by_rows ? 1 : 0, stamp);
     else if (channels == 3)
         hipLaunchKernelGGL(k_frontend<3>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y, by_rows ? 1 : 0);
+                           inv_tiles_y, by_rows ? 1 : 0, stamp);
     else
         hipLaunchKernelGGL(k_frontend<4>, grid, dim3(FE_THREADS), 0, s, src, width, height, src_stride,
                            src_frame_stride, gray_out, score, blur, threshold, c, cand, tile_count, batch, inv_tiles_x, margin,
-                           inv_tiles_y, by_rows ? 1 : 0);
+                           inv_tiles_y, by_rows ? 1 : 0, stamp);
 }
 
 void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t *pyr, uint8_t *pyr_blur,

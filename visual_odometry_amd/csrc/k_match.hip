@@ -70,9 +70,11 @@ __device__ __forceinline__ uint32_t nibble_spread(uint32_t x, int i)
 __global__ __launch_bounds__(KNN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__restrict__ nkp,
             const int *__restrict__ q_slot, const int *__restrict__ t_slot, int kp_stride,
-            uint2 *__restrict__ partial)
+            uint2 *__restrict__ partial, unsigned long long *stamp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_a[3][KNN_TILE * KNN_ROW];  // tiles t, t+1, t+2
+    // (optional: the device wall clock at the start of the launch, for callers that time the matcher)
+    if (stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *stamp = wall_clock64();
     __shared__ uint32_t s_lut[16];  // four descriptor bits -> four bytes +64 (bit set) / -64
 
     const int pair = blockIdx.z, split = blockIdx.y;
@@ -275,9 +277,10 @@ __global__ __launch_bounds__(KNP_THREADS) void k_knn2_popcount(const uint8_t *__
                                                       const int *__restrict__ nkp,
                                                       const int *__restrict__ q_slot,
                                                       const int *__restrict__ t_slot, int kp_stride,
-                                                      uint2 *__restrict__ partial)
+                                                      uint2 *__restrict__ partial, unsigned long long *stamp)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_tile[KNP_TILE * 2];
+    if (stamp && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *stamp = wall_clock64();
 
     const int pair = blockIdx.z, split = blockIdx.y;
     // block-uniform values, kept in scalar registers so that the loops below are controlled by the scalar unit
@@ -344,17 +347,17 @@ __global__ __launch_bounds__(KNP_THREADS) void k_knn2_popcount(const uint8_t *__
 
 void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp, const int *q_slot,
                  const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, bool popcount,
-                 hipStream_t s)
+                 hipStream_t s, unsigned long long *stamp)
 {
     if (popcount) {
         dim3 grid((max_n + KNP_QPB - 1) / KNP_QPB, kKnnSplits, pairs);
         hipLaunchKernelGGL(k_knn2_popcount, grid, dim3(KNP_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot,
-                           t_slot, kp_stride, partial);
+                           t_slot, kp_stride, partial, stamp);
         return;
     }
     dim3 grid((max_n + KNN_QPB - 1) / KNN_QPB, kKnnSplits, pairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(KNN_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot, t_slot,
-                       kp_stride, partial);
+                       kp_stride, partial, stamp);
 }
 
 // ------------------------------------------------------------- finalize

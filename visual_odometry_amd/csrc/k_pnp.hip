@@ -1430,8 +1430,11 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
 // frame), solves and scores their hypotheses and stores (model, inlier count) records; the block that completes a
 // frame's last item replays the sequential acceptance rule over the records in RNG order, stops where the
 // sequential algorithm stops, and refines the pose.  Blocks never wait for each other: a block that finds nothing
-// to claim exits, and a second launch of the same kernel (without frames of its own) sweeps up whatever was
-// published after the last block looked.  The hypotheses, their order and the acceptance logic are those of the
+// to claim exits.  Nothing is left behind that way: a block looks for work after publishing its own items, so it
+// cannot leave while one of them is unclaimed, and whoever claims an item finishes it.  Small batches (the
+// single-stream path: one block per launch) have nobody to share with; there the frames' blocks only publish, and
+// a second launch of the same kernel with many blocks and no frames of its own takes the items side by side.
+// The hypotheses, their order and the acceptance logic are those of the
 // one-block loop, so the results are the same bit for bit; only hypotheses past the final iteration bound are
 // computed in vain.
 // ---------------------------------------------------------------------
@@ -1466,6 +1469,7 @@ struct PnpArgs {
     int *inliers, *pose;
     double *rt;
     int batch;
+    int steal;  // blocks of the first launch claim published work once their own frame is done
     // hand-over (all null: every frame finishes in its own block).  Per frame: state = number of published items
     // (0 until the frame's items, resume record and everything else are in memory), next = items claimed so far
     // (may overshoot), done = items completed.  Zero before the first launch.
@@ -1917,11 +1921,12 @@ __device__ __forceinline__ bool pnp_publish_items(PrShared &S, const PnpArgs &a,
 __device__ __forceinline__ int pnp_claim(PrShared &S, const PnpArgs &a)
 {
     const int tid = threadIdx.x;
+    const int first = (int)(blockIdx.x % (unsigned)a.batch);  // (a sweep launch may have more blocks than frames)
     for (;;) {
         if (tid == 0) S.cand = 0x7fffffff;
         __syncthreads();
         for (int k = tid; k < a.batch; k += PR_THREADS) {
-            int bb = (int)blockIdx.x + k;
+            int bb = first + k;
             if (bb >= a.batch) bb -= a.batch;
             const int st = __hip_atomic_load(&a.state[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st > 0 && __hip_atomic_load(&a.next[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < st)
@@ -1930,7 +1935,7 @@ __device__ __forceinline__ int pnp_claim(PrShared &S, const PnpArgs &a)
         __syncthreads();
         const int k = S.cand;
         if (k == 0x7fffffff) return -1;
-        int bb = (int)blockIdx.x + k;
+        int bb = first + k;
         if (bb >= a.batch) bb -= a.batch;
         if (tid == 0) {
             const int st = __hip_atomic_load(&a.state[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2091,7 +2096,7 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
                            a.pose + b * 4, a.rt + (size_t)b * 6);
             run = own = false;
         }
-        if (!share) break;
+        if (!share || (!sweep && !a.steal)) break;
         const int bb = pnp_claim(S, a);
         if (bb < 0) break;
         b = bb;
@@ -2143,11 +2148,11 @@ size_t pnp_phase2_bytes(int batch, size_t off[4])
 void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_info, int kp_stride,
                        const uint32_t *rng_raw, int rng_len, double fx, double fy, double cx, double cy,
                        int max_iters, double threshold, double confidence, int *inliers, int *pose,
-                       double *rt, int batch, void *phase2, hipStream_t s)
+                       double *rt, int batch, void *phase2, hipStream_t s, bool zeroed)
 {
     const size_t lds = ((sizeof(PrShared) + 15) & ~size_t(15)) + (size_t)kp_stride * (5 * sizeof(float) + 1) + 16;
     PnpArgs a{valid, pts3, bp_info, kp_stride, rng_raw, rng_len, fx, fy, cx, cy, max_iters, threshold, confidence,
-              inliers, pose, rt, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+              inliers, pose, rt, batch, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // handing frames over pays when hypotheses can outnumber two rounds
     const bool share = phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
     if (share) {
@@ -2160,13 +2165,16 @@ void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_i
         a.items = reinterpret_cast<PnpItem *>(p + off[1]);
         a.resume = reinterpret_cast<PnpResume *>(p + off[2]);
         a.hyp = reinterpret_cast<PnpHyp *>(p + off[3]);
-        (void)hipMemsetAsync(a.state, 0, 3 * sizeof(int) * (size_t)batch, s);
+        if (!zeroed) (void)hipMemsetAsync(a.state, 0, 3 * sizeof(int) * (size_t)batch, s);
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pnp_ransac),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // few frames: too few blocks to share the published work among, a second launch brings them
+    const bool few = batch < 64;
+    a.steal = few ? 0 : 1;
     hipLaunchKernelGGL(k_pnp_ransac, dim3(batch), dim3(PR_THREADS), lds, s, a, 0);
-    if (share)  // whatever was published after the last block of the first launch looked for work
-        hipLaunchKernelGGL(k_pnp_ransac, dim3(min(batch, 512)), dim3(PR_THREADS), lds, s, a, 1);
+    if (share && few)
+        hipLaunchKernelGGL(k_pnp_ransac, dim3(min(batch * kPnpItemsPerFrame, 512)), dim3(PR_THREADS), lds, s, a, 1);
 }
 
 }  // namespace vo

@@ -34,8 +34,10 @@ __global__ __launch_bounds__(TA_THREADS) void k_track_ages(const vo_match *__res
                                                            const int *__restrict__ t_slot,
                                                            const int *__restrict__ has_prev, int frames,
                                                            const int *__restrict__ nkp, int *__restrict__ ages,
-                                                           int *__restrict__ filter_flag)
+                                                           int *__restrict__ filter_flag, unsigned long long *stamp)
 {
+    // (optional: the device wall clock at the start of the launch = the end of the matching stages)
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = wall_clock64();
     __shared__ int s_winner[VO_MAX_FEATURES_LIMIT];
     __shared__ int s_age[VO_MAX_FEATURES_LIMIT];  // ages of the frame finished last (slot s_age_slot)
     __shared__ int s_ts[TA_MAX_FRAMES], s_qs[TA_MAX_FRAMES], s_hp[TA_MAX_FRAMES], s_n[TA_MAX_FRAMES],
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(TA_THREADS) void k_track_ages(const vo_match *__res
 
 void launch_track_ages(const vo_match *final_m, const int *info, int kp_stride, const int *q_slot,
                        const int *t_slot, const int *has_prev, int streams, int frames, const int *nkp,
-                       int *ages, int *filter_flag, hipStream_t s)
+                       int *ages, int *filter_flag, hipStream_t s, unsigned long long *stamp)
 {
     hipLaunchKernelGGL(k_track_ages, dim3(streams), dim3(TA_THREADS), 0, s, final_m, info, kp_stride, q_slot,
-                       t_slot, has_prev, frames, nkp, ages, filter_flag);
+                       t_slot, has_prev, frames, nkp, ages, filter_flag, stamp);
 }
 
 // =====================================================================
@@ -172,11 +174,13 @@ __global__ __launch_bounds__(BP_THREADS) void k_filter_backproject(
     const int *__restrict__ ages, const int *__restrict__ filter_flag, const float *__restrict__ depth,
     int width, int height, int depth_stride, size_t depth_frame_stride, double fx, double fy, double cx,
     double cy, vo_match *__restrict__ tracked, vo_match *__restrict__ valid, float *__restrict__ pts3,
-    int *__restrict__ out_info)
+    int *__restrict__ out_info, int *__restrict__ clear3)
 {
     __shared__ int s_wave[BP_THREADS / kWave];
     __shared__ int s_base;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // three words per frame that the next stage wants zeroed ([3][batch], see launch_pnp_ransac)
+    if (clear3 && tid < 3) clear3[tid * gridDim.x + b] = 0;
     const int n = has_prev[b] ? info[b * 4 + 3] : 0;
     const vo_match *m = final_m + (size_t)b * kp_stride;
     vo_match *tr = tracked + (size_t)b * kp_stride;
@@ -236,11 +240,11 @@ void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_
                                const float *depth, int width, int height, int depth_stride,
                                size_t depth_frame_stride, double fx, double fy, double cx, double cy,
                                vo_match *tracked, vo_match *valid, float *pts3, int *out_info, int batch,
-                               hipStream_t s)
+                               hipStream_t s, int *clear3)
 {
     hipLaunchKernelGGL(k_filter_backproject, dim3(batch), dim3(BP_THREADS), 0, s, final_m, info, kp_stride,
                        t_slot, has_prev, nkp, ages, filter_flag, depth, width, height, depth_stride,
-                       depth_frame_stride, fx, fy, cx, cy, tracked, valid, pts3, out_info);
+                       depth_frame_stride, fx, fy, cx, cy, tracked, valid, pts3, out_info, clear3);
 }
 
 // =====================================================================
@@ -294,13 +298,6 @@ __global__ void k_collect(const int *__restrict__ nkp, const int *__restrict__ t
     out[b] = r;
 }
 
-__global__ void k_stamp(unsigned long long *out)
-{
-    if (threadIdx.x == 0) *out = wall_clock64();
-}
-
-void launch_stamp(unsigned long long *out, hipStream_t s) { hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s, out); }
-
 // One block per frame: everything a caller reads back after a batch, gathered into one block of `out` so that a
 // single device-to-host copy delivers it.  All records are whole 32-bit words.
 __global__ __launch_bounds__(256) void k_pack_frames(PackSrc p, PackLayout L, uint8_t *__restrict__ out)
@@ -332,6 +329,80 @@ __global__ __launch_bounds__(256) void k_pack_frames(PackSrc p, PackLayout L, ui
 void launch_pack_frames(const PackSrc &src, PackLayout layout, uint8_t *out, int batch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pack_frames, dim3(batch), dim3(256), 0, s, src, layout, out);
+}
+
+// The end of a batch with packed output in ONE launch: blocks [0, batch) gather their frame's result record (what
+// k_collect does) and pack the frame (k_pack_frames); the blocks behind them copy each stream's last frame into its
+// carry slot (k_carry).  The three touch disjoint data.
+__global__ __launch_bounds__(256) void k_finish_packed(CollectSrc cs, PackSrc p, PackLayout L, uint8_t *__restrict__ out,
+                                                       int batch, vo_kp *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                       int *__restrict__ nkp, int *__restrict__ ages, int streams,
+                                                       int frames, int carry_blocks_x)
+{
+    __shared__ vo_frame_result s_r;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= batch) {
+        const int cb = (int)blockIdx.x - batch;
+        const int s = cb / carry_blocks_x, bx = cb - s * carry_blocks_x;
+        const int dst = s, src = streams + s * frames + frames - 1;
+        const int n = nkp[src];
+        const int i = bx * 256 + tid;
+        const int kp_stride = p.kp_stride;
+        if (i == 0) nkp[dst] = n;
+        if (i < kp_stride) ages[(size_t)dst * kp_stride + i] = ages[(size_t)src * kp_stride + i];
+        if (i < n) {
+            kps[(size_t)dst * kp_stride + i] = kps[(size_t)src * kp_stride + i];
+            const uint4 *sd = reinterpret_cast<const uint4 *>(desc + ((size_t)src * kp_stride + i) * 32);
+            uint4 *dd = reinterpret_cast<uint4 *>(desc + ((size_t)dst * kp_stride + i) * 32);
+            dd[0] = sd[0];
+            dd[1] = sd[1];
+        }
+        return;
+    }
+    const int f = blockIdx.x;
+    if (tid == 0) {
+        vo_frame_result r;
+        r.n_keypoints = cs.nkp[cs.t_slot[f]];
+        r.n_ratio = cs.n_good[f];
+        r.f_found = cs.info[f * 4]; r.f_iters = cs.info[f * 4 + 1]; r.f_inliers = cs.info[f * 4 + 2];
+        r.n_matches = cs.info[f * 4 + 3];
+        r.n_tracked = cs.bp_info[f * 2]; r.n_3d = cs.bp_info[f * 2 + 1];
+        r.pnp_success = cs.pose[f * 4]; r.pnp_inliers = cs.pose[f * 4 + 1]; r.pnp_iters = cs.pose[f * 4 + 2];
+        r.pnp_points = cs.pose[f * 4 + 3];
+        for (int i = 0; i < 3; i++) { r.rvec[i] = cs.rt[f * 6 + i]; r.tvec[i] = cs.rt[f * 6 + 3 + i]; }
+        s_r = r;
+        cs.out[f] = r;
+    }
+    __syncthreads();
+    uint8_t *dst = out + (size_t)f * L.frame_bytes;
+    const vo_frame_result r = s_r;
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(dst);
+    const uint32_t *rs = reinterpret_cast<const uint32_t *>(&s_r);
+    if (tid < (int)(sizeof(vo_frame_result) / 4)) hdr[tid] = rs[tid];
+    if (tid < 6) hdr[sizeof(vo_frame_result) / 4 + tid] = reinterpret_cast<const uint32_t *>(p.stamps)[tid];
+    const int slot = p.t_slot[f];
+    auto copy_words = [&](size_t off, const void *src, int words) {
+        uint32_t *d = reinterpret_cast<uint32_t *>(dst + off);
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+        for (int i = tid; i < words; i += 256) d[i] = s[i];
+    };
+    const int nk = min(r.n_keypoints, L.cap);
+    copy_words(L.off_kps, p.kps + (size_t)slot * p.kp_stride, nk * (int)(sizeof(vo_kp) / 4));
+    copy_words(L.off_desc, p.desc + (size_t)slot * p.kp_stride * 32, nk * 8);
+    const int nm[3] = {min(r.n_matches, L.cap), min(r.n_tracked, L.cap), min(r.n_3d, L.cap)};
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+        copy_words(L.off_m[w], p.m[w] + (size_t)f * p.kp_stride, nm[w] * (int)(sizeof(vo_match) / 4));
+    copy_words(L.off_pts3, p.pts3 + (size_t)f * p.kp_stride * 3, nm[2] * 3);
+    copy_words(L.off_inl, p.inliers + (size_t)f * p.kp_stride, min(r.pnp_inliers, L.cap));
+}
+
+void launch_finish_packed(const CollectSrc &cs, const PackSrc &src, PackLayout layout, uint8_t *out, int batch,
+                          vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int streams, int frames, hipStream_t s)
+{
+    const int bx = (src.kp_stride + 255) / 256;
+    hipLaunchKernelGGL(k_finish_packed, dim3(batch + bx * streams), dim3(256), 0, s, cs, src, layout, out, batch, kps,
+                       desc, nkp, ages, streams, frames, bx);
 }
 
 void launch_collect(const int *nkp, const int *t_slot, const int *n_good, const int *info,

@@ -622,7 +622,9 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
 
     // the kernel chain in two parts: everything that needs the frames only, then everything from the depth plane on
     auto chain_front = [&]() {
-        if (c->packed) launch_stamp(c->d_stamps, c->stream);
+        // with packed output the first block of the detector / matcher / track-age launches stores the device wall
+        // clock: detect = [0, 1), match = [1, 2)
+        c->pending_stamp = c->packed ? c->d_stamps : nullptr;
         if (right) {
             // the right images first, without timing marks: the marks of the detector stages are the left images'
             c->marks_on = false;
@@ -648,19 +650,18 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
                                 c->d_partial, c->d_partial_rev, c->d_st_idx, c->d_st_disp, c->d_st_depth,
                                 reinterpret_cast<uint32_t *>(c->d_depth), b.width, b.height, c->d_st_n, c->stream);
         }
-        if (c->packed) launch_stamp(c->d_stamps + 1, c->stream);
+        c->pending_stamp = c->packed ? c->d_stamps + 1 : nullptr;
         c->enqueue_match(B, b.ratio, b.cross_check != 0, FRansacParams{b.f_threshold, b.f_confidence, b.f_max_iters});
         c->mark(8);
-        if (c->packed) launch_stamp(c->d_stamps + 2, c->stream);
         launch_track_ages(c->d_final, c->d_info, c->kp_stride, c->d_qslot, c->d_tslot, c->d_has_prev, S, F,
-                          c->d_nkp, c->d_ages, c->d_filter_flag, c->stream);
+                          c->d_nkp, c->d_ages, c->d_filter_flag, c->stream, c->packed ? c->d_stamps + 2 : nullptr);
         c->mark(9);
     };
     auto chain_back = [&]() {
         launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
                                   c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
                                   depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
-                                  c->d_bpinfo, B, c->stream);
+                                  c->d_bpinfo, B, c->stream, pnp_share_words(c->d_pnp2));
         if (right)  // the planes go back to all-NaN for the next stereo batch
             launch_stereo_clear(c->d_kps, c->d_nkp, c->kp_stride, S, B, reinterpret_cast<uint32_t *>(c->d_depth),
                                 b.width, b.height, c->stream);
@@ -671,19 +672,24 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         } else
             launch_pnp_ransac(c->d_valid, c->d_pts3, c->d_bpinfo, c->kp_stride, c->d_rng, c->rng_len, b.fx, b.fy,
                               b.cx, b.cy, b.pnp_iters, b.pnp_threshold, b.pnp_confidence, c->d_inliers, c->d_pose,
-                              c->d_rt, B, c->d_pnp2, c->stream);
+                              c->d_rt, B, c->d_pnp2, c->stream, /*zeroed=*/true);
         c->mark(11);
-        launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results, B,
-                       c->stream);
         if (c->packed) {
+            // result records, packed frames and carry slots in one launch; the records reach the host inside the
+            // packed block
+            CollectSrc cs{c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results};
             PackSrc ps{c->d_results, c->d_kps, c->d_desc, c->d_tslot, {c->d_final, c->d_tracked, c->d_valid},
                        c->d_pts3, c->d_inliers, c->d_stamps, c->kp_stride};
-            launch_pack_frames(ps, c->pack, c->d_pack, B, c->stream);
-        }
-        launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
-        (void)hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost, c->stream);
-        if (c->packed)
+            launch_finish_packed(cs, ps, c->pack, c->d_pack, B, c->d_kps, c->d_desc, c->d_nkp, c->d_ages, S, F,
+                                 c->stream);
             (void)hipMemcpyAsync(c->h_pack, c->d_pack, c->pack.frame_bytes * B, hipMemcpyDeviceToHost, c->stream);
+        } else {
+            launch_collect(c->d_nkp, c->d_tslot, c->d_ngood, c->d_info, c->d_bpinfo, c->d_pose, c->d_rt, c->d_results,
+                           B, c->stream);
+            launch_carry(c->d_kps, c->d_desc, c->d_nkp, c->d_ages, c->kp_stride, S, F, c->stream);
+            (void)hipMemcpyAsync(c->h_pinned, c->d_results, sizeof(vo_frame_result) * B, hipMemcpyDeviceToHost,
+                                 c->stream);
+        }
         c->mark(12);
     };
 
@@ -902,6 +908,13 @@ int vo_batch_wait(vo_ctx *c, vo_frame_result *results)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->submitted = false;
+    if (c->packed_valid) {
+        // the result records came up at the head of every packed frame
+        const int B = c->bcfg.n_streams * c->bcfg.frames_per_stream;
+        for (int f = 0; f < B; f++)
+            memcpy(static_cast<vo_frame_result *>(c->h_pinned) + f,
+                   static_cast<const uint8_t *>(c->h_pack) + (size_t)f * c->pack.frame_bytes, sizeof(vo_frame_result));
+    }
     if (results)
         memcpy(results, c->h_pinned, sizeof(vo_frame_result) * c->bcfg.n_streams * c->bcfg.frames_per_stream);
     return VO_OK;

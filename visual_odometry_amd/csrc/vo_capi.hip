@@ -663,7 +663,8 @@ void vo_ctx::enqueue_detect(const uint8_t *src, int w, int h, int src_stride, si
     mark(0);
     launch_frontend(src, w, h, src_stride, src_frame_stride, channels, PlaneBatch{nullptr, 0, 0},
                     PlaneBatch{nullptr, 0, 0}, plane(d_blur), fast_threshold, d_cand, d_cand_count, batch, gc,
-                    stream);
+                    stream, 3, pending_stamp);
+    pending_stamp = nullptr;
     mark(1);
     mark(2);  // no pyramid in this mode
     mark(3);
@@ -760,7 +761,8 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
         launch_frontend(in, L.w, L.h, l == 0 ? src_stride : L.pitch, l == 0 ? src_frame_stride : orb.frame_bytes,
                         l == 0 ? channels : 1, l == 0 ? level(d_pyr, 0) : PlaneBatch{nullptr, 0, 0},
                         PlaneBatch{nullptr, 0, 0}, level(d_pyr_blur, l), fast_threshold, d_orb_cand + L.cand_off,
-                        d_orb_cand_count + L.count_off, batch, gc, stream, kFBorder - 1);
+                        d_orb_cand_count + L.count_off, batch, gc, stream, kFBorder - 1, l == 0 ? pending_stamp : nullptr);
+        if (l == 0) pending_stamp = nullptr;
     };
     fast_level(0);
     mark(1);
@@ -789,7 +791,8 @@ void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacPara
 {
     mark(5);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
-                pairs, matcher_popcount, stream);
+                pairs, matcher_popcount, stream, pending_stamp);
+    pending_stamp = nullptr;
     if (cross_check)  // the same pairs with the roles of query and train swapped
         launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_tslot, d_qslot, kp_stride, d_partial_rev, kp_stride,
                     pairs, matcher_popcount, stream);

@@ -108,6 +108,7 @@ struct vo_ctx {
     void *h_pack = nullptr;
     size_t pack_cap_bytes = 0;            // bytes allocated behind d_pack / h_pack
     unsigned long long *d_stamps = nullptr;
+    unsigned long long *pending_stamp = nullptr;  // stored by the first block of the next detector / matcher launch
     double wall_clock_khz = 0;
     bool use_graph = false;
     hipGraphExec_t graph_exec = nullptr;       // detection, matching, track ages

@@ -104,7 +104,7 @@ void launch_frontend(const uint8_t *src, int width, int height, int src_stride,
                      size_t src_frame_stride, int channels, PlaneBatch gray_out,
                      PlaneBatch score, PlaneBatch blur, int threshold,
                      uint32_t *cand, uint32_t *tile_count, int batch,
-                     GrayCoeffs c, hipStream_t s, int margin = 3);
+                     GrayCoeffs c, hipStream_t s, int margin = 3, unsigned long long *stamp = nullptr);
 
 // launch_frontend for the gray planes of pyramid levels first_level .. nlevels-1 in one launch (input: the gray
 // pyramid, output: the blurred pyramid and the levels' corner lists, laid out as the plan says)
@@ -132,7 +132,8 @@ void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride,
 // popcount: the XOR / popcount kernel on the vector ALU instead of the matrix-core kernel (same results).
 void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp,
                  const int *q_slot, const int *t_slot, int kp_stride,
-                 uint2 *partial, int max_n, int pairs, bool popcount, hipStream_t s);
+                 uint2 *partial, int max_n, int pairs, bool popcount, hipStream_t s,
+                 unsigned long long *stamp = nullptr);
 
 // ImageProcessor stages (reference src/image_processor.cpp:41-79), one plane.
 void launch_hist256(const uint8_t *img, int w, int h, int pitch, uint32_t *hist, hipStream_t s);
@@ -203,7 +204,7 @@ void launch_recover_pose(const double *E, const double *q, int n, double dist, i
 // keypoints from the matches, and the multi-view filter decision.
 void launch_track_ages(const vo_match *final_m, const int *info, int kp_stride, const int *q_slot,
                        const int *t_slot, const int *has_prev, int streams, int frames, const int *nkp,
-                       int *ages, int *filter_flag, hipStream_t s);
+                       int *ages, int *filter_flag, hipStream_t s, unsigned long long *stamp = nullptr);
 
 // Per frame: apply the multi-view filter (-> tracked), then back-project the
 // current points through the depth map (-> valid + pts3). out_info = {n_tracked, n_3d}.
@@ -212,18 +213,24 @@ void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_
                                const float *depth, int width, int height, int depth_stride,
                                size_t depth_frame_stride, double fx, double fy, double cx, double cy,
                                vo_match *tracked, vo_match *valid, float *pts3, int *out_info, int batch,
-                               hipStream_t s);
+                               hipStream_t s, int *clear3 = nullptr);
 
 // cv::solvePnPRansac per frame on (pts3 -> prev 2-D point). pose = {success,
 // n_inliers, iters_run, n_points}; rt = rvec[3], tvec[3].
+// launch_frontend, launch_knn2 and launch_track_ages take an optional `stamp`: the first block of the launch
+// stores the device wall clock there (the packed output's detect / match times), launch_filter_backproject an
+// optional `clear3`: 3 x batch words it zeroes (the hand-over state of launch_pnp_ransac, pnp_share_words()).
 // phase2: device scratch of pnp_phase2_bytes(batch) bytes for the frames that need many hypotheses (their
 // hypotheses are spread over the blocks of the launch and of a follow-up launch); null keeps every frame in its
 // own block.
 void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_info, int kp_stride,
                        const uint32_t *rng_raw, int rng_len, double fx, double fy, double cx, double cy,
                        int max_iters, double threshold, double confidence, int *inliers, int *pose,
-                       double *rt, int batch, void *phase2, hipStream_t s);
+                       double *rt, int batch, void *phase2, hipStream_t s, bool zeroed = false);
 size_t pnp_phase2_bytes(int batch, size_t off[4]);
+// the 3 x batch words at the start of that scratch which must be zero when launch_pnp_ransac runs; with
+// zeroed == true the caller has seen to it (launch_filter_backproject's clear3), otherwise the launch does
+inline int *pnp_share_words(void *phase2) { return static_cast<int *>(phase2); }
 
 // Copy the features and ages of each stream's last frame into its carry slot.
 void launch_carry(vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int kp_stride, int streams, int frames,
@@ -266,8 +273,14 @@ struct PackSrc {
     int kp_stride;
 };
 void launch_pack_frames(const PackSrc &src, PackLayout layout, uint8_t *out, int batch, hipStream_t s);
-// store the device wall clock (constant-rate counter) in *out
-void launch_stamp(unsigned long long *out, hipStream_t s);
+struct CollectSrc {
+    const int *nkp, *t_slot, *n_good, *info, *bp_info, *pose;
+    const double *rt;
+    vo_frame_result *out;
+};
+// launch_collect + launch_pack_frames + launch_carry in one launch
+void launch_finish_packed(const CollectSrc &cs, const PackSrc &src, PackLayout layout, uint8_t *out, int batch,
+                          vo_kp *kps, uint8_t *desc, int *nkp, int *ages, int streams, int frames, hipStream_t s);
 
 #ifdef __HIPCC__
 // Corner keys: (255 - score) << 24 | y << 12 | x.  Ascending key order is score descending, then raster order
