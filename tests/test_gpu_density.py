@@ -1,0 +1,75 @@
+"""Worst-case corner density and the limits of the full detector: uniform noise at HD1080 with threshold 1 and
+the largest key-point budget the library takes (hundreds of thousands of FAST corners per frame, every 128 x 32
+tile list far above its usual fill, the cut score of the selection deep inside a huge class of equal scores),
+through the single-frame operators and through one batched launch, against the oracle bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, N = 1920, 1080, 6144
+
+
+@pytest.fixture(scope="module")
+def noise():
+    rng = np.random.default_rng(6144)
+    return rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def big_ctx():
+    from visual_odometry_amd import capi
+    c = capi.Context(device=0, max_width=W, max_height=H, max_features=N, max_batch=2)
+    yield c
+    c.close()
+
+
+def test_noise_frame_fast_detector_at_the_feature_limit(big_ctx, oracle, noise):
+    k, d = big_ctx.detect(noise[0], N, 1)
+    kr, dr = oracle.detect(noise[0], N, 1)
+    # about one pixel in nine is a strict 3 x 3 maximum of the score map; the budget is a small part of that
+    assert len(kr) > 5000
+    assert np.array_equal(k, kr) and np.array_equal(d, dr)
+
+
+def test_noise_frame_orb_detector_at_the_feature_limit(big_ctx, oracle, noise):
+    k, d = big_ctx.detect_orb(noise[0], nfeatures=N - 64, scale_factor=1.2, nlevels=8, fast_threshold=1, cap=N)
+    kr, dr = oracle.orb_detect(noise[0], nfeatures=N - 64, scale_factor=1.2, nlevels=8, fast_threshold=1)
+    kr, dr = kr[:N], dr[:N]
+    assert len(kr) >= N - 64
+    assert np.array_equal(k, kr) and np.array_equal(d, dr)
+
+
+@pytest.mark.parametrize("levels", [0, 8])
+def test_noise_frames_one_batched_launch(big_ctx, oracle, noise, levels):
+    n = N if levels == 0 else N - 64
+    big_ctx.batch_configure(W, H, 1, n_streams=1, frames_per_stream=2, max_features=n, fast_threshold=1,
+                            orb_levels=levels)
+    big_ctx.batch_submit(noise, None)
+    res = big_ctx.batch_wait()
+    for f in range(2):
+        k, d = big_ctx.batch_features(f)
+        if levels == 0:
+            kr, dr = oracle.detect(noise[f], n, 1)
+        else:
+            kr, dr = oracle.orb_detect(noise[f], nfeatures=n, scale_factor=1.2, nlevels=8, fast_threshold=1)
+            kr, dr = kr[:N], dr[:N]
+        assert res["n_keypoints"][f] == len(kr)
+        assert np.array_equal(k, kr) and np.array_equal(d, dr), (levels, f)
+    # unrelated noise frames: the matcher runs on the full 6144 x 6144 problem and finds next to nothing
+    m, _ = big_ctx.batch_matches(1, 0)
+    assert len(m) < 50
+
+
+def test_orb_level_quota_limit(big_ctx, oracle, noise):
+    """cv::ORB::create(nfeatures, scale, levels) takes any numbers; the full detector here keeps a level's
+    candidates in LDS and takes at most 1792 key points from one level.  3000 / 2.0 / 3 asks level 0 for 1714 and
+    works; 4000 / 2.0 / 3 asks for 2286 and is refused with a message that says so."""
+    from visual_odometry_amd import capi
+    img = noise[1][:720, :1280]
+    k, d = big_ctx.detect_orb(img, nfeatures=3000, scale_factor=2.0, nlevels=3, fast_threshold=20, cap=N)
+    kr, dr = oracle.orb_detect(img, nfeatures=3000, scale_factor=2.0, nlevels=3, fast_threshold=20)
+    assert len(kr) >= 3000 and np.array_equal(k, kr[:N]) and np.array_equal(d, dr[:N])
+    with pytest.raises(capi.VoError) as e:
+        big_ctx.detect_orb(img, nfeatures=4000, scale_factor=2.0, nlevels=3, fast_threshold=20, cap=N)
+    assert e.value.code == capi.VO_ERR_UNSUPPORTED and "1792" in str(e.value)
