@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+# (VO_LIB_PATH: a diagnostic build of the library, see profiles/diag)
+LIB_PATH = os.environ.get("VO_LIB_PATH") or os.path.join(_HERE, "libvo_hip.so")
 
 VO_OK = 0
 VO_ERR_ARG = -1

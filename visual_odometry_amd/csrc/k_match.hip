@@ -221,7 +221,13 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
         chain(1, acc1, start, A, acc0, [&](int ks) { A[ks] = operand(bnext, ks); });
         // block barrier for the LDS tiles only: __syncthreads() would also wait for the packed words of tile
         // t+3, a global load that is meant to stay in flight across the barrier
+#ifdef VO_KNN_NO_BARRIER
+        // timing-only diagnostic build (wrong results: the tiles race): what no wave ever waiting for another at
+        // this point would be worth -- the bound on any finer-grained hand-over (per-tile ready flags)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         bcur = bnext;
     }
     // Set 0 took tile t's keys in step t and is relative to the last tile now.  Set 1 takes tile t-1's keys in
