@@ -405,6 +405,9 @@ def main():
                                HBM_PEAK_GBS, "GB/s"),
             # levels 1..L-1: read the gray level, write its blurred version
             "frontend_upper_levels": ("hbm", Bc * 2 * px_up / 1e9, HBM_PEAK_GBS, "GB/s"),
+            # per-level ranking + orientation (full detector): a 9x9 Harris footprint for each of the 2N best FAST
+            # corners, the radius-15 disc (709 pixels) for each of the N key points kept
+            "select_topn": ("hbm", Bc * (2 * n_kp * 81 + n_kp * 709) / 1e9 if levels else 0.0, HBM_PEAK_GBS, "GB/s"),
             "brief": ("hbm", Bc * n_kp * (512 + 32) / 1e9, HBM_PEAK_GBS, "GB/s"),
             # all-pairs Hamming distance as an int8 matrix product: 256 multiply-adds = 512 operations per
             # descriptor pair on the matrix cores (v_mfma_i32_32x32x32_i8)

@@ -9,12 +9,6 @@
 
 #include "vo_internal.h"
 
-// VO_BLUR_MFMA=1 builds the tile kernel with its 7x7 Gaussian on the matrix pipe (fe_blur_mfma below) instead of the
-// vector-ALU row and column passes.  Same bits; measured on 512 HD720 frames: level 0 1.00 against 0.93 ms, levels
-// 1-7 1.975 against 1.955 ms -- not faster, so it is off.
-#ifndef VO_BLUR_MFMA
-#define VO_BLUR_MFMA 0
-#endif
 
 namespace vo {
 
@@ -231,92 +225,9 @@ __device__ __forceinline__ void hsum7_quad(uint32_t d0, uint32_t d1, uint32_t d2
     h[3] = __builtin_amdgcn_udot4(a3, XA, __builtin_amdgcn_udot4(b3, XB, 0u, false), false);
 }
 
-// ---- the 7x7 Gaussian of a tile on the matrix pipe (VO_BLUR_MFMA) ----
-// Both passes are banded matrix products over int8 operands (v_mfma_i32_16x16x64_i8), one 16-column block of the
-// tile per wave, nothing crosses waves:
-//   row pass     H[r][n] = sum_k (I[r][16 b + k] - 128) * T[k - n - 1] + 128 * 257   (k: 64-column window, 22 used)
-//   column pass  out[q][n] = sum_r H[r][n] * T[r - q - 1], H split into its two bytes (each biased by -128)
-// The accumulator registers of the row pass (column n on the lane, four consecutive rows per lane group) are the
-// K slots of the column pass as they are: slot (lane group g, byte 4 R + i) holds tile row 16 R + 4 g + i, and the
-// weight operand is laid out to match, so no value changes lanes.  Sums are exact integers: same bits as the
-// vector-ALU passes.
-[[maybe_unused]] constexpr int FE_BLUR_ROWS = 48;  // tile rows the three 16-row blocks of the row pass read (rows 40 .. 47: zero weight)
-struct BlurOperands {
-    uint32_t h[64][4];      // row pass B operand: lane -> bytes T[16 g + j - n - 1]
-    uint32_t v[2][64][4];   // column pass B operand of output rows 16 Q + n2
-};
-constexpr int blur_tap(int t)
-{
-    constexpr int taps[7] = {18, 34, 49, 55, 49, 34, 18};
-    return t >= 0 && t <= 6 ? taps[t] : 0;
-}
-constexpr BlurOperands make_blur_operands()
-{
-    BlurOperands o{};
-    for (int lane = 0; lane < 64; lane++) {
-        const int n = lane & 15, g = lane >> 4;
-        for (int j = 0; j < 16; j++) {
-            o.h[lane][j >> 2] |= (uint32_t)blur_tap(16 * g + j - n - 1) << (8 * (j & 3));
-            for (int Q = 0; Q < 2; Q++) {
-                const int R = j >> 2, i = j & 3;
-                const int row = 16 * R + 4 * g + i, out_row = 4 + 16 * Q + n;  // tile rows
-                const int w = R < 3 ? blur_tap(row - out_row + 3) : 0;
-                o.v[Q][lane][j >> 2] |= (uint32_t)w << (8 * (j & 3));
-            }
-        }
-    }
-    return o;
-}
-__device__ const BlurOperands g_blur_operands = make_blur_operands();
-
-typedef int fe_v4i __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void fe_blur_mfma(const uint8_t *s_gray, PlaneBatch blur, int f, int x0, int y0, int height)
-{
-    const int lane = threadIdx.x & 63, b = threadIdx.x >> 6;  // wave b: tile columns 16 b .. 16 b + 15 of the output
-    const int n = lane & 15, g = lane >> 4;
-    const uint4 bh = *reinterpret_cast<const uint4 *>(g_blur_operands.h[lane]);
-    const fe_v4i Bh = {(int)bh.x, (int)bh.y, (int)bh.z, (int)bh.w};
-    // row pass: three 16-row blocks; lane (row n of the block, window bytes 16 g ..) reads 16 bytes
-    uint32_t pa[3], pb[3];  // per block: the high / low bytes of this lane's four row sums, biased by -128
-#pragma unroll
-    for (int R = 0; R < 3; R++) {
-        const uint4 px = *reinterpret_cast<const uint4 *>(&s_gray[(16 * R + n) * FE_PITCH + 16 * b + 16 * g]);
-        const fe_v4i A = {(int)(px.x ^ 0x80808080u), (int)(px.y ^ 0x80808080u), (int)(px.z ^ 0x80808080u),
-                          (int)(px.w ^ 0x80808080u)};
-        const fe_v4i c0 = {128 * 257, 128 * 257, 128 * 257, 128 * 257};
-        const fe_v4i H = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, Bh, c0, 0, 0, 0);  // H[reg] = row 16 R + 4 g + reg, column n
-        pa[R] = (__builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x0c0c0501u) |
-                 __builtin_amdgcn_perm((uint32_t)H[3], (uint32_t)H[2], 0x05010c0cu)) ^ 0x80808080u;
-        pb[R] = (__builtin_amdgcn_perm((uint32_t)H[1], (uint32_t)H[0], 0x0c0c0400u) |
-                 __builtin_amdgcn_perm((uint32_t)H[3], (uint32_t)H[2], 0x04000c0cu)) ^ 0x80808080u;
-    }
-    const fe_v4i Aa = {(int)pa[0], (int)pa[1], (int)pa[2], 0}, Ab = {(int)pb[0], (int)pb[1], (int)pb[2], 0};
-    uint8_t *bp = blur.base + f * blur.plane_stride + (size_t)y0 * blur.pitch + x0 + 16 * b + 4 * g;
-#pragma unroll
-    for (int Q = 0; Q < 2; Q++) {
-        const uint4 bv = *reinterpret_cast<const uint4 *>(g_blur_operands.v[Q][lane]);
-        const fe_v4i Bv = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
-        // high bytes: sum w (a - 128) + 128 * 257; low bytes the same plus the rounding constant and 0xff000000, which
-        // makes the saturating add below clamp byte 2 of the result at 255
-        const fe_v4i ca = {128 * 257, 128 * 257, 128 * 257, 128 * 257};
-        constexpr int kb = (int)(0xff000000u + 128u * 257u + 32768u);
-        const fe_v4i cb = {kb, kb, kb, kb};
-        const fe_v4i Da = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aa, Bv, ca, 0, 0, 0);
-        const fe_v4i Db = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ab, Bv, cb, 0, 0, 0);
-        uint32_t sres[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            sres[i] = __builtin_elementwise_add_sat((uint32_t)Da[i] << 8, (uint32_t)Db[i]);
-        // lane: output row 16 Q + n, columns 4 g .. 4 g + 3 of the wave's block
-        const int yy = y0 + 16 * Q + n;
-        if (yy < height) *reinterpret_cast<uint32_t *>(bp + (size_t)(16 * Q + n) * blur.pitch) = pack_byte2(sres[0], sres[1], sres[2], sres[3]);
-    }
-}
-
 constexpr int FE_TASKS = FE_GROWS * (FE_PITCH / 4);  // 4-pixel staging tasks per tile
 constexpr int FE_TPT = (FE_TASKS + FE_THREADS - 1) / FE_THREADS;  // tasks per thread
-[[maybe_unused]] constexpr int FE_HPAIRS = FE_HROWS / 2;  // row pairs of row sums
+constexpr int FE_HPAIRS = FE_HROWS / 2;  // row pairs of row sums
 static_assert(kTileCap == FE_TW * FE_TH / 4, "a tile emits at most one corner per 2x2 block");
 static_assert(FE_HROWS % 2 == 0 && FE_TH % 2 == 0, "rows are processed in pairs");
 
@@ -574,17 +485,9 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
                                         uint32_t *__restrict__ tile_count, int batch, uint32_t inv_tiles_x,
                                         int margin, int col, int ty, int unused_edge = 0)
 {
-#if VO_BLUR_MFMA
-    // (the matrix-pipe blur reads 48 rows x a 64-byte window per lane group: rows and columns past the staged tile
-    // carry zero weight but must be readable)
-    __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_BLUR_ROWS * FE_PITCH + 64];
-#else
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[FE_GROWS * FE_PITCH];
-#endif
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FE_SROWS * FE_PITCH];
-#if !VO_BLUR_MFMA
     __shared__ __attribute__((aligned(16))) uint32_t s_hpair[FE_HPAIRS * FE_TW];  // row sums of rows (2p, 2p+1)
-#endif
     __shared__ uint16_t s_queue[FE_QCAP + 64];  // + one spare slot per lane for the unconditional stores
     __shared__ uint32_t s_counters[3];  // queue entries, emitted corners, waves done
     uint32_t &s_qcount = s_counters[0], &s_ecount = s_counters[1], &s_done = s_counters[2];
@@ -632,9 +535,6 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     __syncthreads();
     FE_STAMP(3);
     FE_CUT(1);
-#if VO_BLUR_MFMA
-    if (blur.base) fe_blur_mfma(s_gray, blur, f, x0, y0, height);
-#endif
 
     const int gx = tid & 31, gy = tid >> 5;  // 32 quad columns x 16 rows: this thread's quads are at rows gy + 16 k
     const int x = x0 + gx * 4;               // image column of the first pixel of its quads
@@ -759,7 +659,6 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
 
     // ---- Gaussian, row pass: row sums of tile rows 1 .. FE_HROWS, two rows per task, the last threads of
     // the block first so that the waves with fewer queue entries take the second round
-#if !VO_BLUR_MFMA
     if (blur.base) {
 #pragma unroll
         for (int it = 0; it < (FE_HPAIRS * 32 + FE_THREADS - 1) / FE_THREADS; it++) {
@@ -778,7 +677,6 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
             }
         }
     }
-#endif
     FE_STAMP(6);
     __syncthreads();
     FE_STAMP(7);
@@ -827,7 +725,6 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
 
     // ---- Gaussian, column pass: output rows (2m, 2m+1) from the row pairs m .. m+3
     static_assert((FE_TH / 2) * 32 == FE_THREADS, "one pair of output rows per thread");
-#if !VO_BLUR_MFMA
     if (blur.base) {
         const int ct = FE_THREADS - 1 - tid;
         const int m = ct >> 5, tg = ct & 31;
@@ -861,7 +758,6 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
         if (yy < height) *reinterpret_cast<uint32_t *>(bp) = oe;
         if (yy + 1 < height) *reinterpret_cast<uint32_t *>(bp + blur.pitch) = oo;
     }
-#endif
 
 #pragma unroll
     for (int k = 0; k < FE_QPT; k++) {
