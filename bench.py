@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--host-fed", type=int, default=1, help="also measure the host-fed (PCIe-inclusive) rate (0 = skip)")
     ap.add_argument("--facade-latency", type=int, default=1,
                     help="also measure the single-stream latency through the C++ facade (0 = skip)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay each launch's kernel chain as a recorded HIP graph (vo_batch_set_graph) during the "
+                         "timed steps")
     ap.add_argument("--cpu-fast", type=int, default=1,
                     help="also time the CPU baseline of the other detector (the one-level FAST sequence the "
                          "reference node runs) for the record (0 = skip)")
@@ -204,8 +207,9 @@ def main():
     kitti = args.config == "kitti8"
     NC = max(1, args.contexts) if not kitti else 1
     assert args.streams % NC == 0, "--streams must be a multiple of --contexts"
-    # the ranks of one node share its host cores: each renders with its share of the workers
-    render_workers = max(1, min(args.render_workers, os.cpu_count() or 1) // world)
+    # the ranks of one node share its host cores: each renders with up to --render-workers processes out of its
+    # share of them (a node with 16 cores per GPU keeps all 16 at any number of ranks)
+    render_workers = max(1, min(args.render_workers, (os.cpu_count() or 1) // world))
     if kitti:
         # configs[3]: eight streams in all; rank r owns streams r, r + world, ... and renders exactly those (a stream's
         # seed does not depend on the number of ranks)
@@ -259,6 +263,8 @@ def main():
             return np.concatenate([c.batch_wait() for c in ctxs])
 
         r = None
+        for c in ctxs:
+            c.batch_set_graph(bool(args.graph))
         for _ in range(warmup):
             r = step()
         barrier()
@@ -269,6 +275,8 @@ def main():
         dt = time.perf_counter() - t0
         fps_ = shard.aggregate_fps(B * steps, dt, dist, red_dev)
         dt = shard.max_over_ranks(dt, dist, red_dev)
+        for c in ctxs:
+            c.batch_set_graph(False)  # (per-stage events need plain launches)
         # (context 0 alone, so that one launch's duration is not stretched by another context's kernels)
         ctx.batch_set_timing(True)
         acc_ = {}
@@ -359,6 +367,49 @@ def main():
                     "pose_success_rate": float(hres["pnp_success"].mean())}
         hctx.close()
         del bufs, fp_, dp_
+
+        # The same with the compact input format (an extension of this library, vo_batch_submit_depth16): gray 8-bit
+        # frames and 16-bit millimetre depth, 3 bytes per pixel over the link instead of 8
+        gray_h = np.stack([ctx.gray(fr) for fr in frames_h[:hb]])
+        d16_h = np.clip(np.rint(depth_h[:hb]), 0, 65535).astype(np.uint16)
+        gp_ = torch.from_numpy(gray_h).pin_memory()
+        zp_ = torch.from_numpy(d16_h.view(np.int16)).pin_memory()
+        bufs = [(torch.empty_like(gp_, device="cuda"), torch.empty_like(zp_, device="cuda")) for _ in range(2)]
+        gctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=hb)
+        gctx.set_matcher(args.matcher)
+        gctx.batch_configure(W, H, 1, n_streams=hs, frames_per_stream=F, max_features=args.features,
+                             fast_threshold=20, camera=K, orb_levels=levels)
+
+        def upload16(k):
+            with torch.cuda.stream(copy_stream):
+                bufs[k % 2][0].copy_(gp_, non_blocking=True)
+                bufs[k % 2][1].copy_(zp_, non_blocking=True)
+
+        def run16(k):
+            fb, db = bufs[k % 2]
+            gctx.batch_submit_ptr(fb.data_ptr(), W, W * H, db.data_ptr(), W, W * H, depth16=True)
+
+        upload16(0)
+        copy_stream.synchronize()
+        run16(0); upload16(1); gctx.batch_wait(); copy_stream.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(1, n_h + 1):
+            run16(k)
+            upload16(k + 1)
+            gres = gctx.batch_wait()
+            copy_stream.synchronize()
+        torch.cuda.synchronize()
+        dt_g = time.perf_counter() - t0
+        bytes16 = gp_.numel() + 2 * zp_.numel()
+        host_fed["gray_depth16"] = {
+            "value": hb * n_h / dt_g, "unit": "frames/s", "pcie_gb_per_s": bytes16 * n_h / dt_g / 1e9,
+            "bytes_per_frame": bytes16 // hb,
+            "how": "gray 8-bit frames + 16-bit millimetre depth (vo_batch_submit_depth16, an extension: the "
+                   "reference's camera interface delivers BGRA + float32), same double-buffered upload",
+            "pose_success_rate": float(gres["pnp_success"].mean())}
+        gctx.close()
+        del bufs, gp_, zp_
 
     # and on a flat wall (no depth relief at all): every PnP inlier set is planar, so the pose refinement starts from
     # a homography instead of the DLT

@@ -383,6 +383,14 @@ int vo_batch_set_previous(vo_ctx *ctx, int stream, const vo_kp *kps,
 int vo_batch_submit(vo_ctx *ctx, const uint8_t *frames, int row_stride,
                     size_t frame_stride, const float *depth,
                     int depth_row_stride, size_t depth_frame_stride);
+/* vo_batch_submit with the depth planes as 16-bit unsigned millimetres (0 = no measurement) instead of float32:
+ * every depth value z is used as (float)z, everything else is the same call.  An extension for host-fed
+ * deployments, where the upload is what limits the frame rate: gray 8-bit frames (channels = 1) with 16-bit depth
+ * are 3 bytes per pixel against the 8 of BGRA + float32 depth.  The reference's camera interface delivers BGRA and
+ * float32 millimetres (src/zed_interface.cpp:84-91); depth sensors themselves report 16-bit millimetres.
+ * depth_row_stride / depth_frame_stride are in elements. */
+int vo_batch_submit_depth16(vo_ctx *ctx, const uint8_t *frames, int row_stride, size_t frame_stride,
+                            const uint16_t *depth_mm, int depth_row_stride, size_t depth_frame_stride);
 /* Parameters of the stereo matcher (see vo_stereo_depth). */
 typedef struct {
     double baseline;      /* distance between the cameras, in the unit the depth is wanted in (mm for the pose stage) */

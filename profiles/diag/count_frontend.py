@@ -21,8 +21,10 @@ seq = synth.make_sequence(cam, 2, seed=2000, channels=4, scene=synth.Scene(2000,
 S, F = 16, 16
 frames = torch.from_numpy(np.concatenate([seq["frames"]] * (S * F // 2))).cuda()
 depth = torch.from_numpy(np.concatenate([seq["depth"]] * (S * F // 2))).cuda()
-ctx = capi.Context(0, cam.width, cam.height, 2000, S * F)
-ctx.batch_configure(cam.width, cam.height, 4, S, F, max_features=2000, camera=(cam.fx, cam.fy, cam.cx, cam.cy))
+ctx = capi.Context(0, cam.width, cam.height, 2064, S * F)
+levels = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 8: the full detector (level 0 + the upper-level launch)
+ctx.batch_configure(cam.width, cam.height, 4, S, F, max_features=2000, camera=(cam.fx, cam.fy, cam.cx, cam.cy),
+                    orb_levels=levels)
 for _ in range(3):
     ctx.batch_submit_ptr(frames.data_ptr(), cam.width * 4, cam.width * 4 * cam.height, depth.data_ptr(), cam.width,
                          cam.width * cam.height)

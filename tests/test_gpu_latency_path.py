@@ -200,3 +200,43 @@ def test_failed_reconfigure_with_packed_output_leaves_the_context_as_it_was():
         assert (first["n_keypoints"] > 100).all()
     finally:
         c.close()
+
+
+def test_depth16_gray_input_equals_float_depth(ctx, oracle):
+    """vo_batch_submit_depth16: gray 8-bit frames with 16-bit millimetre depth (3 bytes per pixel over the link
+    instead of 8) give what the float path gives on the same numbers -- and both what the oracle gives."""
+    from oracle.pipeline import OracleStream
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F = 2, 3
+    seqs = [synth.make_sequence(cam, F, seed=4300 + s, channels=3) for s in range(S)]
+    gray = np.concatenate([np.stack([oracle.gray(f) for f in q["frames"]]) for q in seqs])
+    d16 = np.concatenate([np.clip(np.rint(q["depth"]), 0, 65535).astype(np.uint16) for q in seqs])
+    d16[:, ::7, ::5] = 0                       # holes: no measurement
+    d32 = d16.astype(np.float32)
+    ctx.batch_set_packed_output(False)
+    ctx.batch_set_graph(False)
+    out = []
+    for depth in (d32, d16):
+        ctx.batch_configure(cam.width, cam.height, 1, n_streams=S, frames_per_stream=F, max_features=1000, camera=K)
+        ctx.batch_submit(gray, depth)
+        res = ctx.batch_wait()
+        lists = [(ctx.batch_matches(b, 2), ctx.batch_inliers(b)) for b in range(S * F)]
+        out.append((res, lists))
+    (r32, l32), (r16, l16) = out
+    assert r32.tobytes() == r16.tobytes()
+    assert int(r32["pnp_success"].sum()) == S * (F - 1)
+    for (m32, i32), (m16, i16) in zip(l32, l16):
+        assert np.array_equal(m32[0], m16[0]) and np.array_equal(m32[1], m16[1]) and np.array_equal(i32, i16)
+    # against the oracle, stream by stream
+    for s in range(S):
+        ref = OracleStream(K, 1000, 20)
+        for f in range(F):
+            b = s * F + f
+            r = ref.process(gray[b], d32[b])
+            m, p3 = l16[b][0]
+            assert np.array_equal(m, r["valid"]) and np.array_equal(p3, r["pts3"])
+            assert bool(r16["pnp_success"][b]) == r["pnp_success"]
+            if r["pnp_success"]:
+                assert np.array_equal(l16[b][1], r["inliers"])
+                assert np.abs(r16["rvec"][b] - r["rvec"]).max() < 1e-6

@@ -110,6 +110,7 @@ EXPORTS = {
     "vo_batch_set_camera": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double]),
     "vo_batch_set_previous": (C.c_int, [_P, C.c_int, _P, _P, C.c_int]),
     "vo_batch_submit": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _P, C.c_int, C.c_size_t]),
+    "vo_batch_submit_depth16": (C.c_int, [_P, _P, C.c_int, C.c_size_t, _P, C.c_int, C.c_size_t]),
     "vo_batch_submit_stereo": (C.c_int, [_P, _P, _P, C.c_int, C.c_size_t, C.POINTER(VoStereoCfg)]),
     "vo_batch_get_stereo": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "vo_batch_wait": (C.c_int, [_P, _P]),
@@ -397,24 +398,29 @@ class Context:
         self._check(self._lib.vo_batch_reset(self._h))
 
     def batch_submit_ptr(self, frames_ptr, row_stride, frame_stride, depth_ptr=None, depth_row_stride=0,
-                         depth_frame_stride=0):
-        """Raw pointers (ints), e.g. device memory owned by the caller."""
-        self._check(self._lib.vo_batch_submit(self._h, frames_ptr, row_stride, frame_stride, depth_ptr,
-                                              depth_row_stride, depth_frame_stride))
+                         depth_frame_stride=0, depth16=False):
+        """Raw pointers (ints), e.g. device memory owned by the caller; depth16: the depth planes are uint16 mm."""
+        fn = self._lib.vo_batch_submit_depth16 if depth16 else self._lib.vo_batch_submit
+        self._check(fn(self._h, frames_ptr, row_stride, frame_stride, depth_ptr, depth_row_stride, depth_frame_stride))
 
     def batch_submit(self, frames: np.ndarray, depth: np.ndarray | None = None):
-        """frames: (batch, H, W[, C]) uint8 host array; depth: (batch, H, W) float32."""
+        """frames: (batch, H, W[, C]) uint8 host array; depth: (batch, H, W) float32, or uint16 millimetres."""
         frames = np.ascontiguousarray(frames, np.uint8)
         cfg = self._bcfg
         assert frames.shape[0] == self._batch and frames.shape[1] == cfg.height and frames.shape[2] == cfg.width
         row = cfg.width * cfg.channels
         self._keep = [frames]
         dptr, drow, dfr = None, 0, 0
+        fn = self._lib.vo_batch_submit
         if depth is not None:
-            depth = np.ascontiguousarray(depth, np.float32)
+            if depth.dtype == np.uint16:   # 16-bit millimetres: the extension entry point
+                depth = np.ascontiguousarray(depth)
+                fn = self._lib.vo_batch_submit_depth16
+            else:
+                depth = np.ascontiguousarray(depth, np.float32)
             self._keep.append(depth)
             dptr, drow, dfr = _ptr(depth), cfg.width, cfg.width * cfg.height
-        self._check(self._lib.vo_batch_submit(self._h, _ptr(frames), row, row * cfg.height, dptr, drow, dfr))
+        self._check(fn(self._h, _ptr(frames), row, row * cfg.height, dptr, drow, dfr))
 
     def batch_submit_stereo(self, left, right, baseline, band=2.0, min_disp=1.0, max_disp=256.0, ratio=0.8):
         """left / right: (batch, H, W[, C]) uint8 host arrays, or (pointer, row_stride, frame_stride) tuples of

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_filter_backproject(
     const int *__restrict__ ages, const int *__restrict__ filter_flag, const float *__restrict__ depth,
     int width, int height, int depth_stride, size_t depth_frame_stride, double fx, double fy, double cx,
     double cy, vo_match *__restrict__ tracked, vo_match *__restrict__ valid, float *__restrict__ pts3,
-    int *__restrict__ out_info, int *__restrict__ clear3)
+    int *__restrict__ out_info, int *__restrict__ clear3, int depth_u16)
 {
     __shared__ int s_wave[BP_THREADS / kWave];
     __shared__ int s_base;
@@ -208,7 +208,11 @@ __global__ __launch_bounds__(BP_THREADS) void k_filter_backproject(
     __syncthreads();
     if (tid == 0) s_base = 0;
     __syncthreads();
-    const float *dimg = depth ? depth + b * depth_frame_stride : nullptr;
+    // (depth_u16: the planes hold uint16 millimetres, 0 = no measurement; strides are in elements either way)
+    const float *dimg = depth ? (depth_u16 ? reinterpret_cast<const float *>(reinterpret_cast<const uint16_t *>(depth) +
+                                                                                b * depth_frame_stride)
+                                           : depth + b * depth_frame_stride)
+                              : nullptr;
     for (int i0 = 0; i0 < n_tr; i0 += BP_THREADS) {
         const int i = i0 + tid;
         bool keep = false;
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(BP_THREADS) void k_filter_backproject(
             mm = tr[i];
             const int u = (int)roundf(mm.cx), v = (int)roundf(mm.cy);
             if (u >= 0 && u < width && v >= 0 && v < height) {
-                z = dimg[(size_t)v * depth_stride + u];
+                z = depth_u16 ? (float)reinterpret_cast<const uint16_t *>(dimg)[(size_t)v * depth_stride + u]
+                              : dimg[(size_t)v * depth_stride + u];
                 if (!(isnan(z) || isinf(z) || z <= 0.0f || z < 50.0f || z > 20000.0f)) {
                     X = (float)(((double)mm.cx - cx) * (double)z / fx);
                     Y = (float)(((double)mm.cy - cy) * (double)z / fy);
@@ -240,11 +245,11 @@ void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_
                                const float *depth, int width, int height, int depth_stride,
                                size_t depth_frame_stride, double fx, double fy, double cx, double cy,
                                vo_match *tracked, vo_match *valid, float *pts3, int *out_info, int batch,
-                               hipStream_t s, int *clear3)
+                               hipStream_t s, int *clear3, bool depth_u16)
 {
     hipLaunchKernelGGL(k_filter_backproject, dim3(batch), dim3(BP_THREADS), 0, s, final_m, info, kp_stride,
                        t_slot, has_prev, nkp, ages, filter_flag, depth, width, height, depth_stride,
-                       depth_frame_stride, fx, fy, cx, cy, tracked, valid, pts3, out_info, clear3);
+                       depth_frame_stride, fx, fy, cx, cy, tracked, valid, pts3, out_info, clear3, depth_u16 ? 1 : 0);
 }
 
 // =====================================================================

@@ -445,8 +445,10 @@ static uint8_t *stage_area(vo_ctx *c, size_t bytes)
 // matcher instead of the caller
 static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride, const float *depth,
                         int depth_row_stride, size_t depth_frame_stride, const uint8_t *right,
-                        const vo_stereo_cfg *st)
+                        const vo_stereo_cfg *st, bool depth_u16 = false)
 {
+    // (depth_u16: `depth` really points at uint16 millimetres; strides stay in elements)
+    const size_t dsz = depth_u16 ? sizeof(uint16_t) : sizeof(float);
     if (!c) return VO_ERR_ARG;
     if (!c->configured) return bfail(c, VO_ERR_STATE, "vo_batch_submit: configure first");
     if (c->submitted) return bfail(c, VO_ERR_STATE, "vo_batch_submit: previous batch not waited for");
@@ -484,7 +486,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const bool right_on_host = right && !is_device_ptr(right);
     const uint8_t *src = frames;
     const size_t frames_bytes = (size_t)row_bytes * b.height * B;
-    const size_t depth_bytes = sizeof(float) * (size_t)b.width * b.height * B;
+    const size_t depth_bytes = dsz * (size_t)b.width * b.height * B;
     const bool frames_host = !is_device_ptr(frames);
     const bool depth_host_mem = depth && b.enable_pose && !right && !is_device_ptr(depth);
     // ordinary (not pinned) host memory goes through the context's own pinned staging area
@@ -533,9 +535,9 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             w.src = reinterpret_cast<const uint8_t *>(depth);
             w.stage = stage + 2 * frames_bytes;
             w.dst = reinterpret_cast<uint8_t *>(c->d_depth);
-            w.row_bytes = sizeof(float) * b.width; w.rows = b.height;
-            w.row_stride = sizeof(float) * (size_t)depth_row_stride;
-            w.plane_stride = sizeof(float) * depth_frame_stride;
+            w.row_bytes = dsz * b.width; w.rows = b.height;
+            w.row_stride = dsz * (size_t)depth_row_stride;
+            w.plane_stride = dsz * depth_frame_stride;
             w.count = B;
             w.wait_frames = frames_host;
             w.posted = true; w.go = false; w.cancel = false; w.issued = false; w.err = 0;
@@ -586,8 +588,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_frames, 0));
         }
         int rc0 = upload_planes(c, reinterpret_cast<uint8_t *>(c->d_depth), reinterpret_cast<const uint8_t *>(depth_host),
-                                sizeof(float) * b.width, b.height, sizeof(float) * depth_row_stride_host,
-                                sizeof(float) * depth_frame_stride_host, B, c->copy_stream);
+                                dsz * b.width, b.height, dsz * depth_row_stride_host,
+                                dsz * depth_frame_stride_host, B, c->copy_stream);
         if (rc0) return rc0;
         HIP_TRY(c, hipEventRecord(c->ev_depth, c->copy_stream));
         return VO_OK;
@@ -661,7 +663,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         launch_filter_backproject(c->d_final, c->d_info, c->kp_stride, c->d_tslot, c->d_has_prev, c->d_nkp,
                                   c->d_ages, c->d_filter_flag, dsrc, b.width, b.height, depth_row_stride,
                                   depth_frame_stride, b.fx, b.fy, b.cx, b.cy, c->d_tracked, c->d_valid, c->d_pts3,
-                                  c->d_bpinfo, B, c->stream, pnp_share_words(c->d_pnp2));
+                                  c->d_bpinfo, B, c->stream, pnp_share_words(c->d_pnp2), depth_u16 && !right);
         if (right)  // the planes go back to all-NaN for the next stereo batch
             launch_stereo_clear(c->d_kps, c->d_nkp, c->kp_stride, S, B, reinterpret_cast<uint32_t *>(c->d_depth),
                                 b.width, b.height, c->stream);
@@ -705,7 +707,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             key.st_baseline = st->baseline; key.st_band = st->band; key.st_min_disparity = st->min_disparity;
             key.st_max_disparity = st->max_disparity; key.st_ratio = st->ratio;
         }
-        key.packed = c->packed; key.popcount = c->matcher_popcount;
+        key.packed = c->packed; key.popcount = c->matcher_popcount; key.depth_u16 = depth_u16;
         if (c->graph_exec && !(key == c->graph_key)) c->drop_graph();
         key.generation = c->generation;
         if (!c->graph_exec) {
@@ -765,6 +767,13 @@ int vo_batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t fra
 {
     return batch_submit(c, frames, row_stride, frame_stride, depth, depth_row_stride, depth_frame_stride, nullptr,
                         nullptr);
+}
+
+int vo_batch_submit_depth16(vo_ctx *c, const uint8_t *frames, int row_stride, size_t frame_stride,
+                            const uint16_t *depth_mm, int depth_row_stride, size_t depth_frame_stride)
+{
+    return batch_submit(c, frames, row_stride, frame_stride, reinterpret_cast<const float *>(depth_mm), depth_row_stride,
+                        depth_frame_stride, nullptr, nullptr, /*depth_u16=*/true);
 }
 
 int vo_batch_submit_stereo(vo_ctx *c, const uint8_t *left, const uint8_t *right, int row_stride, size_t frame_stride,

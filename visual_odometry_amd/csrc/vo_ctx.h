@@ -125,7 +125,7 @@ struct vo_ctx {
         unsigned long long generation = 0;
         double st_baseline = 0;
         float st_band = 0, st_min_disparity = 0, st_max_disparity = 0, st_ratio = 0;
-        bool packed = false, popcount = false;
+        bool packed = false, popcount = false, depth_u16 = false;
         bool operator==(const GraphKey &o) const
         {
             return frames == o.frames && depth == o.depth && right == o.right && row_stride == o.row_stride &&
@@ -133,7 +133,7 @@ struct vo_ctx {
                    depth_frame_stride == o.depth_frame_stride && generation == o.generation &&
                    st_baseline == o.st_baseline && st_band == o.st_band && st_min_disparity == o.st_min_disparity &&
                    st_max_disparity == o.st_max_disparity && st_ratio == o.st_ratio && packed == o.packed &&
-                   popcount == o.popcount;
+                   popcount == o.popcount && depth_u16 == o.depth_u16;
         }
     } graph_key{};
     // forget the recorded chain; every caller that frees, reallocates or re-plans something the chain refers to

@@ -213,7 +213,7 @@ void launch_filter_backproject(const vo_match *final_m, const int *info, int kp_
                                const float *depth, int width, int height, int depth_stride,
                                size_t depth_frame_stride, double fx, double fy, double cx, double cy,
                                vo_match *tracked, vo_match *valid, float *pts3, int *out_info, int batch,
-                               hipStream_t s, int *clear3 = nullptr);
+                               hipStream_t s, int *clear3 = nullptr, bool depth_u16 = false);
 
 // cv::solvePnPRansac per frame on (pts3 -> prev 2-D point). pose = {success,
 // n_inliers, iters_run, n_points}; rt = rvec[3], tvec[3].
