@@ -79,7 +79,7 @@ void launch_gray(const uint8_t *src, int width, int height, int src_stride, size
 // ----------------------- fused gray + FAST + NMS + emit + blur (one tile)
 
 constexpr int FE_TW = 128;             // interior tile width
-constexpr int FE_TH = 32;              // interior tile height
+constexpr int FE_TH = kTileH;          // interior tile height
 constexpr int FE_PITCH = FE_TW + 16;   // LDS row: image x0-4 .. x0+TW+11, 16-B aligned
 constexpr int FE_GROWS = FE_TH + 8;    // gray rows: image y0-4 .. y0+TH+3
 constexpr int FE_SROWS = FE_TH + 2;    // score rows: image y0-1 .. y0+TH
@@ -388,46 +388,62 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
     if constexpr (CN == 1 && PATH == FE_INSIDE) {
         // gray input, tile and apron inside the image: the rows are copied as 16-byte pieces (4-byte aligned in
         // global memory, 16-byte aligned in LDS), one piece per thread
-        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR;
-        static_assert(NP <= FE_THREADS && FE_PITCH % 16 == 0, "one 16-byte piece per thread");
-        static_assert(FE_SROWS * FE_PITCH / 16 <= FE_THREADS, "one 16-byte piece of the score tile per thread");
+        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR, PPT = (NP + FE_THREADS - 1) / FE_THREADS;
+        static_assert(FE_PITCH % 16 == 0, "whole 16-byte pieces");
         typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-        const int i = min(tid, NP - 1);
-        const int tr = i / PPR, tp = i - tr * PPR;
-        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(img + (size_t)(tile.y0 - 4 + tr) * src_stride +
-                                                                (tile.x0 - 4 + 16 * tp));
-        if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
+        u32x4_a4 v[PPT];
+        int at[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int i = min(tid + u * FE_THREADS, NP - 1);
+            const int tr = i / PPR, tp = i - tr * PPR;
+            at[u] = tr * FE_PITCH + 16 * tp;
+            v[u] = *reinterpret_cast<const u32x4_a4 *>(img + (size_t)(tile.y0 - 4 + tr) * src_stride +
+                                                       (tile.x0 - 4 + 16 * tp));
+        }
+        for (int i = tid; i < FE_SROWS * FE_PITCH / 16; i += FE_THREADS) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0, 0, 0, 0);
         if (tid < 3) s_counters[tid] = 0;
         FE_STAMP(1);
-        if (tid < NP) *reinterpret_cast<uint4 *>(&s_gray[tr * FE_PITCH + 16 * tp]) = make_uint4(v.x, v.y, v.z, v.w);
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (tid + u * FE_THREADS < NP)
+                *reinterpret_cast<uint4 *>(&s_gray[at[u]]) = make_uint4(v[u].x, v[u].y, v[u].z, v[u].w);
         return;
     }
     if constexpr (CN == 1 && PATH == FE_BORDER) {
         // gray input, border tile of an aligned image: the same 16-byte pieces with the row reflected; a piece
         // that crosses the left or right image edge is gathered byte by byte
-        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR;
+        constexpr int PPR = FE_PITCH / 16, NP = FE_GROWS * PPR, PPT = (NP + FE_THREADS - 1) / FE_THREADS;
         typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-        const int i = min(tid, NP - 1);
-        const int tr = i / PPR, tp = i - tr * PPR;
-        const uint8_t *row = img + (size_t)reflect101_near(tile.y0 - 4 + tr, height) * src_stride;
-        const int xb = tile.x0 - 4 + 16 * tp;
-        uint32_t w[4];
-        if (xb >= 0 && xb + 16 <= width) {
-            const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(row + xb);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else {
+        uint32_t w[PPT][4];
+        int at[PPT];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                w[q] = 0;
+        for (int u = 0; u < PPT; u++) {
+            const int i = min(tid + u * FE_THREADS, NP - 1);
+            const int tr = i / PPR, tp = i - tr * PPR;
+            at[u] = tr * FE_PITCH + 16 * tp;
+            const uint8_t *row = img + (size_t)reflect101_near(tile.y0 - 4 + tr, height) * src_stride;
+            const int xb = tile.x0 - 4 + 16 * tp;
+            if (xb >= 0 && xb + 16 <= width) {
+                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(row + xb);
+                w[u][0] = v.x; w[u][1] = v.y; w[u][2] = v.z; w[u][3] = v.w;
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    w[q] |= (uint32_t)row[reflect101_near(xb + 4 * q + j, width)] << (8 * j);
+                for (int q = 0; q < 4; q++) {
+                    w[u][q] = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        w[u][q] |= (uint32_t)row[reflect101_near(xb + 4 * q + j, width)] << (8 * j);
+                }
             }
         }
-        if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < FE_SROWS * FE_PITCH / 16; i += FE_THREADS) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0, 0, 0, 0);
         if (tid < 3) s_counters[tid] = 0;
         FE_STAMP(1);
-        if (tid < NP) *reinterpret_cast<uint4 *>(&s_gray[tr * FE_PITCH + 16 * tp]) = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (tid + u * FE_THREADS < NP)
+                *reinterpret_cast<uint4 *>(&s_gray[at[u]]) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
         return;
     }
     FePre<CN> pre[FE_TPT];
@@ -442,8 +458,8 @@ __device__ __forceinline__ void fe_stage(uint8_t *s_gray, uint8_t *s_score, uint
         at[u] = tr * FE_PITCH + tq * 4;
         if (i < FE_TASKS) packed[u] = fe_issue<CN, PATH>(pre[u], img, src_stride, width, height, tile, tr, tq);
     }
-    static_assert(FE_SROWS * FE_PITCH / 16 <= FE_THREADS && FE_PITCH % 16 == 0, "one 16-byte piece of the score tile per thread");
-    if (tid < FE_SROWS * FE_PITCH / 16) reinterpret_cast<uint4 *>(s_score)[tid] = make_uint4(0, 0, 0, 0);
+    static_assert(FE_PITCH % 16 == 0, "whole 16-byte pieces");
+    for (int i = tid; i < FE_SROWS * FE_PITCH / 16; i += FE_THREADS) reinterpret_cast<uint4 *>(s_score)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 3) s_counters[tid] = 0;
     FE_STAMP(1);
 #pragma unroll
@@ -724,9 +740,11 @@ __device__ __forceinline__ void fe_tile(const uint8_t *__restrict__ src, int wid
     FE_STAMP(8);
 
     // ---- Gaussian, column pass: output rows (2m, 2m+1) from the row pairs m .. m+3
-    static_assert((FE_TH / 2) * 32 == FE_THREADS, "one pair of output rows per thread");
-    if (blur.base) {
-        const int ct = FE_THREADS - 1 - tid;
+    static_assert((FE_TH / 2) * 32 % FE_THREADS == 0, "whole rounds of one pair of output rows per thread");
+    if (blur.base)
+#pragma unroll
+    for (int cr = 0; cr < (FE_TH / 2) * 32 / FE_THREADS; cr++) {
+        const int ct = FE_THREADS - 1 - tid + cr * FE_THREADS;
         const int m = ct >> 5, tg = ct & 31;
         uint4 P[4];
 #pragma unroll

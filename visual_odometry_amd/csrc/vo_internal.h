@@ -15,7 +15,10 @@ constexpr int kResizeRowPad = 32;  // rows of a resize tile: the row tables of t
 constexpr int kKnnSplits = 2;      // train-set splits per query block
 constexpr int kFBorder = 31;       // ORB edgeThreshold
 constexpr int kBriefReach = 18;    // the rotated rBRIEF pattern samples at most this far from a key point
-constexpr int kTileW = 128, kTileH = 32;  // tile of the fused image kernel
+#ifndef VO_TILE_H
+#define VO_TILE_H 32   // (64 builds the tile kernel with 128 x 64 tiles: four quads per thread)
+#endif
+constexpr int kTileW = 128, kTileH = VO_TILE_H;  // tile of the fused image kernel
 constexpr int kTileCap = kTileW * kTileH / 4;  // corners one tile can emit (3x3 strict maxima: one per 2x2 block)
 inline int tiles_of(int w, int h) { return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
 constexpr int kOrbMaxLevels = 8;   // pyramid levels of the full ORB detector
