@@ -477,6 +477,9 @@ def main():
         # process): used only when they were taken at this launch size; null where the counter is uncalibrated
         stages_pmc, traffic_source = committed_traffic(Bc)
         measured = {k: v.get("bytes") for k, v in stages_pmc.items()}
+        if measured.get("select_topn_rank") is not None and measured.get("select_topn_finish") is not None:
+            # the stage is two kernels: per-level ranking (Harris footprints) and orientation (radius-15 discs)
+            measured["select_topn"] = measured["select_topn_rank"] + measured["select_topn_finish"]
         busy = {k: v.get("valu_busy") for k, v in stages_pmc.items()}
         if busy.get(dominant) is not None:
             # measured vector-ALU occupancy of the dominant kernel (SQ_ACTIVE_INST_VALU pass kept under

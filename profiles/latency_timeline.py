@@ -21,8 +21,9 @@ def main(path, frames_back=2):
         for row in db.execute(q):
             ev.append((row[0], row[1], "C copy %s B" % (row[2] if size_col else "?")))
     ev.sort()
-    # a frame ends with the copies behind k_carry: the events between the carry kernels of two consecutive frames
-    carries = [i for i, x in enumerate(ev) if "k_carry" in x[2]]
+    # a frame ends with the copy behind its last kernel (k_finish_packed; k_carry without packed output): the events
+    # between those kernels of two consecutive frames
+    carries = [i for i, x in enumerate(ev) if "k_finish_packed" in x[2] or "k_carry" in x[2]]
     if len(carries) >= frames_back + 2:
         i0 = carries[-2 - frames_back] + 1
         i1 = carries[-1 - frames_back] + 1
