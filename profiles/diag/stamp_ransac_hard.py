@@ -2,7 +2,7 @@
 """RANSAC stages on the moving-objects scene: distribution of the iteration counts over the frames of one launch
 and, from the diagnostic build (make -C profiles/diag), the cycle stamps of the F-RANSAC and PnP kernels.
 
-    python3 profiles/diag/stamp_ransac_hard.py [movers] [streams]
+    python3 profiles/diag/stamp_ransac_hard.py [movers] [streams] [flat]
 """
 import ctypes as C
 import os
@@ -27,7 +27,12 @@ def main():
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     F = 16
     cam = synth.CONFIG_CAMERAS["hd720"]
-    f, d, _ = synth.make_pingpong_batch(cam, S, F, 52000, channels=4, relief=2.0, movers=movers, workers=16)
+    flat = len(sys.argv) > 3 and sys.argv[3] == "flat"   # the flat-wall scene of the benchmark instead
+    if flat:
+        f, d, _ = synth.make_pingpong_batch(cam, S, F, 72000, channels=4, relief=0.0, movers=0, workers=16,
+                                            tilt=(0.08, -0.05))
+    else:
+        f, d, _ = synth.make_pingpong_batch(cam, S, F, 52000, channels=4, relief=2.0, movers=movers, workers=16)
     frames = torch.from_numpy(f).cuda()
     depth = torch.from_numpy(d).cuda()
     ctx = capi.Context(0, cam.width, cam.height, 2064, S * F)
@@ -74,6 +79,22 @@ def main():
             print(f"PnP   {nme:34s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
         tot = t[:, 10] - t[:, 0]
         print("PnP whole block: median %d p90 %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max()))
+        if hasattr(raw, "vo_debug_pnp_blocks"):
+            pb = np.zeros((1024, 8), np.uint64)
+            raw.vo_debug_pnp_blocks.argtypes = [C.c_void_p]
+            assert raw.vo_debug_pnp_blocks(pb.ctypes.data) == 0
+            pb = pb[:S * F].astype(np.int64)
+            t0 = pb[:, 0].min()
+            own, end = pb[:, 1] - t0, pb[:, 2] - t0
+            print("PnP blocks: handed over %d, items solved %d, items skipped %d, frames resumed %d" %
+                  (pb[:, 3].sum(), pb[:, 4].sum(), pb[:, 5].sum(), pb[:, 6].sum()))
+            print("PnP blocks: own frame done (cycles from the first start) median %d p90 %d max %d; block done median %d "
+                  "p90 %d max %d; latest start %d" % (np.median(own[own > 0]), np.percentile(own[own > 0], 90), own.max(),
+                                                      np.median(end), np.percentile(end, 90), end.max(),
+                                                      (pb[:, 0] - t0).max()))
+            h = pb[:, 3] > 0
+            if h.any():
+                print("PnP handed-over frames' blocks: done at", sorted(end[h].tolist())[:12])
         fr = np.zeros((256, 16), np.uint64)
         raw.vo_debug_fr_stamps.argtypes = [C.c_void_p]
         assert raw.vo_debug_fr_stamps(fr.ctypes.data) == 0

@@ -21,6 +21,7 @@
 // fp64 throughout, evaluated with contraction disabled.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "vo_internal.h"
 
@@ -685,7 +686,7 @@ struct PrShared {
     long long pos;
     int scan_base;
     int lm_ok;
-    int cand, claim_item, claim_n, last;   // claiming published work items
+    int cand, claim_item, claim_n, claim_hint, last;   // claiming published work items
     unsigned long long acc_mask[PR_WAVES];  // accepted hypotheses of a replay
     // planar initialisation (homography) of the refinement
     int init_mode;        // 0 DLT, 1 homography (planar inliers), 2 five non-planar inliers: keep the RANSAC pose
@@ -1322,8 +1323,25 @@ extern "C" int vo_debug_pnp_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_stamps), sizeof(unsigned long long) * 256 * 16);
 }
+// per block of the first 1024: start, own frame done, block done (cycles); handed over, items solved, items skipped,
+// frames resumed
+__device__ unsigned long long g_pnp_blocks[1024 * 8];
+#define PNP_BLOCK(i, v)                                                                  \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_pnp_blocks[blockIdx.x * 8 + (i)] = (v); \
+    } while (0)
+#define PNP_BLOCK_ADD(i, v)                                                              \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_pnp_blocks[blockIdx.x * 8 + (i)] += (v); \
+    } while (0)
+extern "C" int vo_debug_pnp_blocks(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_blocks), sizeof(unsigned long long) * 1024 * 8);
+}
 #else
 #define PNP_STAMP(i) do { } while (0)
+#define PNP_BLOCK(i, v) do { } while (0)
+#define PNP_BLOCK_ADD(i, v) do { } while (0)
 #endif
 
 // solve hypotheses first_h .. first_h + per_wave - 1 of the round (those below nc), one per group of PR_GROUP
@@ -1427,8 +1445,11 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
 // handed over instead: its block chains the RNG stream into the start positions of every hypothesis the current
 // iteration bound still admits (the bound only ever shrinks), publishes them as work items of up to PR_CHUNK
 // hypotheses, and looks for work itself.  Every block whose own frame is finished claims published items (of any
-// frame), solves and scores their hypotheses and stores (model, inlier count) records; the block that completes a
-// frame's last item replays the sequential acceptance rule over the records in RNG order, stops where the
+// frame), solves and scores their hypotheses and stores (model, inlier count) records.  Whenever an item is
+// completed, its block looks at the items before it: once a gap-free run of items from the first one on is complete,
+// the sequential acceptance rule can be replayed over their records in RNG order; if the replay shows that the
+// sequential loop stops inside them (or every item is complete), that block takes the frame back -- exactly one
+// does -- stops where the
 // sequential algorithm stops, and refines the pose.  Blocks never wait for each other: a block that finds nothing
 // to claim exits.  Nothing is left behind that way: a block looks for work after publishing its own items, so it
 // cannot leave while one of them is unclaimed, and whoever claims an item finishes it.  Small batches (the
@@ -1436,7 +1457,9 @@ __device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img
 // a second launch of the same kernel with many blocks and no frames of its own takes the items side by side.
 // The hypotheses, their order and the acceptance logic are those of the
 // one-block loop, so the results are the same bit for bit; only hypotheses past the final iteration bound are
-// computed in vain.
+// computed in vain, and few of those: every completed item lowers a per-frame bound from its best inlier count
+// (the sequential loop's bound can only be lower), and items that start at or behind it, or belong to a frame
+// that has been taken back, are dropped unsolved when they are claimed.
 // ---------------------------------------------------------------------
 
 // hypothesis records of a handed-over frame: kPnpSpecMax per frame
@@ -1472,8 +1495,11 @@ struct PnpArgs {
     int steal;  // blocks of the first launch claim published work once their own frame is done
     // hand-over (all null: every frame finishes in its own block).  Per frame: state = number of published items
     // (0 until the frame's items, resume record and everything else are in memory), next = items claimed so far
-    // (may overshoot), done = items completed.  Zero before the first launch.
+    // (may overshoot), done = bit i set: item i is complete.  Zero before the first launch.
     int *state, *next, *done;
+    // per frame, set by the publisher (no clearing needed): hint = an upper bound of the iteration count at which the
+    // sequential loop stops, lowered by every finished item; resumed = a block has taken the frame back
+    int *hint, *resumed;
     PnpItem *items;  // kPnpItemsPerFrame per frame
     PnpResume *resume;
     PnpHyp *hyp;
@@ -1909,7 +1935,9 @@ __device__ __forceinline__ bool pnp_publish_items(PrShared &S, const PnpArgs &a,
         PnpResume &r = a.resume[b];
         for (int i = 0; i < 6; i++) r.best[i] = S.best[i];
         r.pos = S.pos; r.iter = S.iter; r.niters = S.niters; r.max_good = S.max_good; r.n_spec = covered;
-        __threadfence();  // items and resume record before the word that announces them
+        __hip_atomic_store(&a.hint[b], r.niters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.resumed[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();  // items, resume record and hint before the word that announces them
         __hip_atomic_store(&a.state[b], n_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return true;
@@ -1943,25 +1971,30 @@ __device__ __forceinline__ int pnp_claim(PrShared &S, const PnpArgs &a)
             S.claim_item = i < st ? i : -1;  // somebody else took the last one in between: look again
             S.claim_n = st;
             __threadfence();  // what the publisher wrote before `state` is read after this
+            // (items are claimed in ascending order: every item finished by now lies before this one, so the bound
+            // they have set holds at this item's first hypothesis)
+            S.claim_hint = __hip_atomic_load(&a.hint[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (a frame that has been taken back needs none of its remaining items)
+            if (__hip_atomic_load(&a.resumed[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) S.claim_hint = 0;
         }
         __syncthreads();
         if (S.claim_item >= 0) return bb;
     }
 }
 
-// Replay of cv::RANSACPointSetRegistrator::run's acceptance rule over the n_spec stored hypotheses of frame b, in
-// RNG order: a hypothesis is accepted when its count beats every earlier one (a prefix maximum, found by all
+// Replay of cv::RANSACPointSetRegistrator::run's acceptance rule over the first n_hyps stored hypotheses of frame
+// b, in RNG order: a hypothesis is accepted when its count beats every earlier one (a prefix maximum, found by all
 // threads at once); one lane then walks the accepted ones, moving the iteration bound, and finds the index at
 // which the sequential loop would have stopped.  Leaves S as that loop would (S.done = 1 when it stopped inside the
 // stored hypotheses).  Every thread calls it; ends with a barrier.
-__device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b, int n)
+__device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b, int n, int n_hyps)
 {
     static_assert(kPnpSpecMax <= PR_THREADS, "one stored hypothesis per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PnpResume r = a.resume[b];
     const PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
     int c = -1;
-    if (tid < r.n_spec && hy[tid].ok > 0) c = hy[tid].count;
+    if (tid < n_hyps && hy[tid].ok > 0) c = hy[tid].count;
     int incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1980,7 +2013,7 @@ __device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b,
     if (tid == 0) {
         for (int i = 0; i < 6; i++) S.best[i] = r.best[i];
         int N = r.niters, max_good = r.max_good;
-        int prev = 0, final_iter = r.iter + r.n_spec;
+        int prev = 0, final_iter = r.iter + n_hyps;
         bool done = false;
         // between two accepted hypotheses the bound N is constant: the loop stops at the first index j of the
         // stretch with iter + 1 = r.iter + j + 1 >= N
@@ -1999,7 +2032,7 @@ __device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b,
         }
         if (!done) {
             const int j = max(prev, N - r.iter - 1);
-            if (j <= r.n_spec - 1) { done = true; final_iter = r.iter + j + 1; }
+            if (j <= n_hyps - 1) { done = true; final_iter = r.iter + j + 1; }
         }
         S.pos = r.pos; S.iter = final_iter; S.niters = N; S.max_good = max_good; S.done = done ? 1 : 0;
     }
@@ -2027,6 +2060,8 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
     bool own = false;    // ... and it is this block's own frame (it may still be handed over)
 
     PNP_STAMP(0);
+    PNP_BLOCK(0, __builtin_amdgcn_s_memtime());
+    for (int i = 3; i < 7; i++) PNP_BLOCK(i, 0ull);
     if (!sweep) {
         n = min(a.bp_info[b * 2 + 1], kp_stride);
         const vo_match *vm = a.valid + (size_t)b * kp_stride;
@@ -2091,25 +2126,48 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
             if (!S.done) pnp_ransac_rounds(S, obj, img, n, a, thr2, own && share);
             bool handed = false;
             if (S.done == 2) handed = pnp_publish_items(S, a, b, n);
+            if (handed) PNP_BLOCK(3, 1ull);
+            if (!own) PNP_BLOCK_ADD(6, 1ull);
             if (!handed)
                 pnp_finish(S, obj, img, msk, n, fx, fy, cx, cy, thr2, a.inliers + (size_t)b * kp_stride,
                            a.pose + b * 4, a.rt + (size_t)b * 6);
+            if (own) PNP_BLOCK(1, __builtin_amdgcn_s_memtime());
             run = own = false;
         }
+        PNP_BLOCK(2, __builtin_amdgcn_s_memtime());
         if (!share || (!sweep && !a.steal)) break;
         const int bb = pnp_claim(S, a);
         if (bb < 0) break;
         b = bb;
         n = min(a.bp_info[b * 2 + 1], kp_stride);
-        const PnpItem it = a.items[(size_t)b * kPnpItemsPerFrame + S.claim_item];
+        const int item = S.claim_item;
+        const PnpItem it = a.items[(size_t)b * kPnpItemsPerFrame + item];
         const int n_items = S.claim_n;
+        const PnpResume rs = a.resume[b];
+        // The sequential loop stops at an iteration count no later than the bound the finished items have set.  An
+        // item whose first hypothesis lies at or behind it is never looked at by the replay -- nor is any later
+        // item: the block takes all that are still unclaimed and records them as empty.
+        const bool skip = rs.iter + it.first >= S.claim_hint;
+        int bits = 1 << item;  // items this block completes
         __syncthreads();  // the previous frame's points and S.claim_* are no longer read
-        pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img, msk);
-        if (tid == 0) S.pos = it.pos;
-        __syncthreads();
-        pnp_chain_round(S, n, a.rng_raw, a.rng_len, it.count);
-        pnp_solve_score(S, obj, img, n, PR_PER_WAVE, fx, fy, cx, cy, thr2);
-        {
+        if (skip) PNP_BLOCK_ADD(5, 1ull); else PNP_BLOCK_ADD(4, 1ull);
+        if (skip) {
+            if (tid == 0) S.cand = atomicAdd(&a.next[b], kPnpItemsPerFrame + 1);  // (>= n_items when others took the rest)
+            __syncthreads();
+            PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax;
+            // hypotheses of this item, and from the first unclaimed item on (contiguous up to n_spec)
+            for (int h = it.first + tid; h < it.first + it.count; h += PR_THREADS) { hy[h].ok = 0; hy[h].count = 0; }
+            if (S.cand < n_items) {
+                bits |= ((1 << n_items) - 1) & ~((1 << S.cand) - 1);
+                const int from = a.items[(size_t)b * kPnpItemsPerFrame + S.cand].first;
+                for (int h = from + tid; h < rs.n_spec; h += PR_THREADS) { hy[h].ok = 0; hy[h].count = 0; }
+            }
+        } else {
+            pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img, msk);
+            if (tid == 0) S.pos = it.pos;
+            __syncthreads();
+            pnp_chain_round(S, n, a.rng_raw, a.rng_len, it.count);
+            pnp_solve_score(S, obj, img, n, PR_PER_WAVE, fx, fy, cx, cy, thr2);
             const int nc = S.nchunk;  // == it.count: the same window, the same chain
             PnpHyp *hy = a.hyp + (size_t)b * kPnpSpecMax + it.first;
             if (tid < nc) {
@@ -2118,18 +2176,43 @@ __global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
                 hy[tid].count = ok ? S.counts[tid] : 0;
                 hy[tid].ok = ok ? 1 : 0;
             }
+            if (tid == 0) {
+                // the best count of this item bounds the iteration count from here on (the running best of the
+                // sequential loop is at least this, and the bound only falls with the count)
+                int cmax = 0;
+                for (int h = 0; h < nc; h++)
+                    if (S.ok[h]) cmax = max(cmax, S.counts[h]);
+                if (cmax > max(rs.max_good, 4))
+                    atomicMin(&a.hint[b], pnp_update_num_iters(a.confidence, (double)(n - cmax) / n, 5, rs.niters));
+            }
         }
-        __threadfence();  // the records before the completion count
+        __threadfence();  // the records before the completion bits
         __syncthreads();
         if (tid == 0) {
-            S.last = atomicAdd(&a.done[b], 1) + 1 == n_items;
-            __threadfence();  // the other items' records (counted before this one) are read after this
+            const int m = atomicOr(&a.done[b], bits) | bits;
+            __threadfence();  // the other items' records (completed before these) are read after this
+            // items 0 .. p-1 are complete: their hypotheses can be replayed, whatever the later items are doing
+            S.claim_n = __builtin_ctz(~m);
         }
         __syncthreads();
-        if (S.last) {
-            // this was the frame's last item: its points are in LDS already
-            pnp_replay(S, a, b, n);
-            run = true;
+        const int p = S.claim_n;
+        if (p > 0 && !__hip_atomic_load(&a.resumed[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const PnpItem lastp = a.items[(size_t)b * kPnpItemsPerFrame + p - 1];
+            pnp_replay(S, a, b, n, p == n_items ? rs.n_spec : lastp.first + lastp.count);
+            // The frame goes on as soon as the sequential loop is known to stop inside the complete items (or all
+            // items are complete): one block takes it back, the items still out are of no interest any more.
+            if (S.done || p == n_items) {
+                if (tid == 0) S.last = atomicCAS(&a.resumed[b], 0, 1) == 0;
+                __syncthreads();
+                if (S.last) {
+                    if (skip) {
+                        pnp_load_points(a.valid + (size_t)b * kp_stride, a.pts3 + (size_t)b * kp_stride * 3, n, obj, img,
+                                        msk);
+                        __syncthreads();
+                    }
+                    run = true;
+                }
+            }
         }
     }
 }
@@ -2138,7 +2221,7 @@ size_t pnp_phase2_bytes(int batch, size_t off[4])
 {
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~size_t(255); return at; };
-    off[0] = take(3 * sizeof(int) * (size_t)batch);                                // state, next, done
+    off[0] = take(5 * sizeof(int) * (size_t)batch);                                // state, next, done, hint, resumed
     off[1] = take(sizeof(PnpItem) * (size_t)batch * kPnpItemsPerFrame);            // items
     off[2] = take(sizeof(PnpResume) * (size_t)batch);                              // resume
     off[3] = take(sizeof(PnpHyp) * (size_t)batch * kPnpSpecMax);                   // hyp
@@ -2152,9 +2235,11 @@ void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_i
 {
     const size_t lds = ((sizeof(PrShared) + 15) & ~size_t(15)) + (size_t)kp_stride * (5 * sizeof(float) + 1) + 16;
     PnpArgs a{valid, pts3, bp_info, kp_stride, rng_raw, rng_len, fx, fy, cx, cy, max_iters, threshold, confidence,
-              inliers, pose, rt, batch, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+              inliers, pose, rt, batch, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // handing frames over pays when hypotheses can outnumber two rounds
-    const bool share = phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
+    // (VO_PNP_SHARE=0: every frame stays in its own block, for comparisons)
+    static const bool share_ok = !(getenv("VO_PNP_SHARE") && getenv("VO_PNP_SHARE")[0] == '0');
+    const bool share = share_ok && phase2 != nullptr && max_iters > PR_FIRST + PR_CHUNK;
     if (share) {
         size_t off[4];
         (void)pnp_phase2_bytes(batch, off);
@@ -2162,6 +2247,8 @@ void launch_pnp_ransac(const vo_match *valid, const float *pts3, const int *bp_i
         a.state = reinterpret_cast<int *>(p + off[0]);
         a.next = a.state + batch;
         a.done = a.next + batch;
+        a.hint = a.done + batch;
+        a.resumed = a.hint + batch;
         a.items = reinterpret_cast<PnpItem *>(p + off[1]);
         a.resume = reinterpret_cast<PnpResume *>(p + off[2]);
         a.hyp = reinterpret_cast<PnpHyp *>(p + off[3]);
