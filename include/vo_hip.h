@@ -435,9 +435,13 @@ int vo_batch_get_inliers(vo_ctx *ctx, int frame, int32_t *inliers, int *n_out);
  * ONE device-to-host copy of all blocks into pinned memory; after
  * vo_batch_wait(), vo_batch_get_packed() hands out pointers into that memory
  * (valid until the next submit or configure on this context; no copy, no GPU
- * call).  detect_ms / match_ms are the GPU times of the detector stages and
- * of kNN + ratio + F-RANSAC for the whole batch (device wall clock), what the
- * reference measures around detectFeatures / matchFeatures (:30-40).
+ * call).  detect_ms / match_ms are DEVICE times (differences of the GPU's
+ * wall clock, stamped by the kernels themselves) of the detector stages and
+ * of kNN + ratio + F-RANSAC for the whole batch: they take the place of the
+ * host timers the reference puts around detectFeatures / matchFeatures
+ * (:30-40) but do not contain the upload of the frame, the launch overhead
+ * or the download of the results; a caller that wants the host view times
+ * vo_batch_submit .. vo_batch_wait itself.
  * Only for small batches: batch x (128 + 156 x feature capacity) bytes may not
  * exceed 32 MiB (VO_ERR_ARG otherwise). */
 typedef struct {
