@@ -363,62 +363,110 @@ static int upload_planes(vo_ctx *c, uint8_t *dst, const uint8_t *src, size_t row
     return VO_OK;
 }
 
-// Pack count planes of rows x row_bytes bytes (rows row_stride, planes plane_stride bytes apart) into dst.
-static void pack_planes(uint8_t *dst, const uint8_t *src, size_t row_bytes, int rows, size_t row_stride,
-                        size_t plane_stride, int count)
+// Calling thread of vo_batch_submit only: queue the copy of every chunk of the job whose pieces are all packed -- by
+// whichever thread --, in order; with `block`, wait for the chunks that are not and return when all copies are
+// queued.  Returns the first HIP error (the remaining copies are then dropped).
+int vo_ctx::stager_send(StageJob &j, bool block)
 {
-    const size_t plane_bytes = row_bytes * (size_t)rows;
-    if (row_stride == row_bytes && (count == 1 || plane_stride == plane_bytes)) {
-        memcpy(dst, src, plane_bytes * (size_t)count);
-        return;
+    while (j.sent < j.n_chunks) {
+        const int ch = j.sent;
+        const int need = std::min((int)StageJob::kChunkPieces, j.n_pieces - ch * StageJob::kChunkPieces);
+        while (j.packed[ch].load(std::memory_order_acquire) < need) {
+            if (!block) return j.err;
+            __builtin_ia32_pause();
+        }
+        const size_t off = (size_t)ch * StageJob::kChunk, len = std::min(StageJob::kChunk, j.total - off);
+        if (j.err == 0) {
+            const hipError_t e = hipMemcpyAsync(j.dst + off, j.stage + off, len, hipMemcpyHostToDevice, j.stream);
+            if (e != hipSuccess) j.err = (int)e;
+        }
+        j.sent++;
     }
-    for (int i = 0; i < count; i++)
-        for (int r = 0; r < rows; r++)
-            memcpy(dst + i * plane_bytes + (size_t)r * row_bytes, src + i * plane_stride + (size_t)r * row_stride,
-                   row_bytes);
+    return j.err;
+}
+
+// Pack pieces of a staging job into pinned memory until none is left to take.  The calling thread (`caller`) sends
+// chunks as they become complete and returns when the whole job is on its way; helpers only pack.
+int vo_ctx::stager_work(StageJob &j, bool caller)
+{
+    const size_t plane_bytes = j.row_bytes * (size_t)j.rows;
+    const bool linear = j.row_stride == j.row_bytes && (j.count == 1 || j.plane_stride == plane_bytes);
+    for (;;) {
+        const int i = j.next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= j.n_pieces) break;
+        const size_t done = (size_t)i * StageJob::kPiece, len = std::min(StageJob::kPiece, j.total - done);
+        if (linear) {
+            memcpy(j.stage + done, j.src + done, len);
+        } else {
+            size_t o = done;
+            while (o < done + len) {  // row by row out of the padded source
+                const size_t pl = o / plane_bytes, in_plane = o - pl * plane_bytes;
+                const size_t row = in_plane / j.row_bytes, col = in_plane - row * j.row_bytes;
+                const size_t n = std::min(j.row_bytes - col, done + len - o);
+                memcpy(j.stage + o, j.src + pl * j.plane_stride + row * j.row_stride + col, n);
+                o += n;
+            }
+        }
+        j.packed[i / StageJob::kChunkPieces].fetch_add(1, std::memory_order_release);
+        if (caller) (void)stager_send(j, false);
+    }
+    return caller ? stager_send(j, true) : 0;
 }
 
 void vo_ctx::stager_loop()
 {
     (void)hipSetDevice(device);
-    DepthStager &w = stager;
+    StagePool &w = stager;
+    uint64_t seen = 0;
     std::unique_lock<std::mutex> lk(w.m);
     for (;;) {
-        w.cv.wait(lk, [&] { return w.posted || w.quit; });
+        w.cv.wait(lk, [&] { return w.quit || w.epoch != seen; });
         if (w.quit) return;
-        w.posted = false;
+        seen = w.epoch;
+        const int n = w.n_jobs;
+        w.active++;
         lk.unlock();
-        pack_planes(w.stage, w.src, w.row_bytes, w.rows, w.row_stride, w.plane_stride, w.count);
+        for (int k = 0; k < n; k++) (void)stager_work(w.jobs[k], false);
         lk.lock();
-        w.cv.wait(lk, [&] { return w.go || w.quit; });
-        if (w.quit) return;
-        w.go = false;
-        hipError_t e = hipSuccess;
-        if (!w.cancel) {
-            lk.unlock();
-            // behind the frames' copy: two copies at once would share the link and delay the frames
-            if (w.wait_frames) e = hipStreamWaitEvent(copy_stream, ev_frames, 0);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(w.dst, w.stage, w.row_bytes * (size_t)w.rows * w.count, hipMemcpyHostToDevice,
-                                   copy_stream);
-            if (e == hipSuccess) e = hipEventRecord(ev_depth, copy_stream);
-            lk.lock();
-        }
-        w.err = (int)e;
-        w.issued = true;
-        w.cv.notify_all();
+        if (--w.active == 0) w.cv.notify_all();
     }
+}
+
+// The caller has filled in jobs[0 .. n_jobs): wake the helpers (started on first use; VO_STAGE_THREADS = 0..3
+// helpers, default 1: with the source in cache one helper already keeps the packing ahead of the link, and every
+// further one adds its wake-up to the call; a deployment whose frames come from cold memory may want more).
+void vo_ctx::stager_post(int n_jobs)
+{
+    StagePool &w = stager;
+    static const int want = [] {
+        const char *e = getenv("VO_STAGE_THREADS");
+        int n = e ? atoi(e) : 1;
+        const int cores = (int)std::thread::hardware_concurrency();
+        if (cores > 0) n = std::min(n, cores - 1);
+        return std::max(0, std::min(n, (int)StagePool::kMaxHelpers));
+    }();
+    while (w.n_threads < want) {
+        w.th[w.n_threads] = std::thread([this] { stager_loop(); });
+        w.n_threads++;
+    }
+    {
+        std::lock_guard<std::mutex> g(w.m);
+        w.n_jobs = n_jobs;
+        w.epoch++;
+    }
+    w.cv.notify_all();
 }
 
 void vo_ctx::stager_stop()
 {
-    if (!stager.th.joinable()) return;
+    if (stager.n_threads == 0) return;
     {
         std::lock_guard<std::mutex> g(stager.m);
         stager.quit = true;
     }
     stager.cv.notify_all();
-    stager.th.join();
+    for (int i = 0; i < stager.n_threads; i++) stager.th[i].join();
+    stager.n_threads = 0;
 }
 
 // Pinned staging for batches that come from ordinary host memory: room for the frames (twice with a right image)
@@ -498,63 +546,62 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     static const bool own_stage = !(getenv("VO_STAGE") && getenv("VO_STAGE")[0] == '0');
     if (own_stage && (stage_frames || stage_right || stage_depth))
         stage = stage_area(c, 2 * frames_bytes + depth_bytes);  // (null: too large, the runtime stages)
-    // a depth plane in ordinary memory is packed by the helper thread from now on, beside the work of this one
-    const bool depth_by_helper = stage_depth && stage != nullptr;
-    struct StagerGuard {  // whatever happens below, a posted job is brought to its end before this call returns
-        vo_ctx::DepthStager *w = nullptr;
-        bool released = false;
-        void release(bool cancel)
+    // Planes in ordinary memory are packed and sent in pieces by this thread and the context's helpers
+    const bool pool_frames = stage_frames && stage != nullptr;
+    const bool pool_depth = stage_depth && stage != nullptr;
+    struct PoolGuard {  // whatever happens below, a posted job is brought to its end before this call returns
+        vo_ctx *c;
+        int n = 0;
+        ~PoolGuard()
         {
-            if (!w || released) return;
-            released = true;
-            {
-                std::lock_guard<std::mutex> g(w->m);
-                w->cancel = cancel;
-                w->go = true;
-            }
-            w->cv.notify_all();
+            for (int k = 0; k < n; k++) (void)c->stager_work(c->stager.jobs[k], true);
         }
-        int finish()  // waits until the helper has queued (or dropped) the copy; its HIP status
-        {
-            if (!w) return 0;
-            release(true);
-            std::unique_lock<std::mutex> lk(w->m);
-            w->cv.wait(lk, [&] { return w->issued; });
-            w->issued = false;
-            vo_ctx::DepthStager *done = w;
-            w = nullptr;
-            return done->err;
+    } pool{c};
+    int job_frames = -1, job_depth = -1;
+    if (pool_frames || pool_depth) {
+        vo_ctx::StagePool &w = c->stager;
+        {   // helpers that are still on their way out of the previous call's jobs
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv.wait(lk, [&] { return w.active == 0; });
         }
-        ~StagerGuard() { (void)finish(); }
-    } helper;
-    if (depth_by_helper) {
-        vo_ctx::DepthStager &w = c->stager;
-        if (!w.th.joinable()) w.th = std::thread([c] { c->stager_loop(); });
-        {
-            std::lock_guard<std::mutex> g(w.m);
-            w.src = reinterpret_cast<const uint8_t *>(depth);
-            w.stage = stage + 2 * frames_bytes;
-            w.dst = reinterpret_cast<uint8_t *>(c->d_depth);
-            w.row_bytes = dsz * b.width; w.rows = b.height;
-            w.row_stride = dsz * (size_t)depth_row_stride;
-            w.plane_stride = dsz * depth_frame_stride;
-            w.count = B;
-            w.wait_frames = frames_host;
-            w.posted = true; w.go = false; w.cancel = false; w.issued = false; w.err = 0;
+        auto fill = [&](vo_ctx::StageJob &j, const uint8_t *from, uint8_t *via, uint8_t *to, size_t rb, size_t rstride,
+                        size_t pstride, hipStream_t stream) {
+            j.src = from; j.stage = via; j.dst = to;
+            j.row_bytes = rb; j.rows = b.height; j.row_stride = rstride; j.plane_stride = pstride; j.count = B;
+            j.total = rb * (size_t)b.height * B;
+            j.n_pieces = (int)((j.total + vo_ctx::StageJob::kPiece - 1) / vo_ctx::StageJob::kPiece);
+            j.n_chunks = (j.n_pieces + vo_ctx::StageJob::kChunkPieces - 1) / vo_ctx::StageJob::kChunkPieces;
+            j.stream = stream;
+            j.next.store(0);
+            for (int k = 0; k < j.n_chunks; k++) j.packed[k].store(0);
+            j.sent = 0; j.err = 0;
+        };
+        int n = 0;
+        if (pool_frames) {
+            fill(w.jobs[n], frames, stage, c->d_in, (size_t)row_bytes, (size_t)row_stride, frame_stride, c->stream);
+            job_frames = n++;
         }
-        w.cv.notify_all();
-        helper.w = &w;
+        if (pool_depth) {
+            fill(w.jobs[n], reinterpret_cast<const uint8_t *>(depth), stage + 2 * frames_bytes,
+                 reinterpret_cast<uint8_t *>(c->d_depth), dsz * b.width, dsz * (size_t)depth_row_stride,
+                 dsz * depth_frame_stride, c->copy_stream);
+            job_depth = n++;
+        }
+        pool.n = n;
+        c->stager_post(n);
     }
     if (frames_host) {
-        int rc0 = upload_planes(c, c->d_in, frames, row_bytes, b.height, row_stride, frame_stride, B, c->stream,
-                                stage_frames ? stage : nullptr);
-        if (rc0) return rc0;
+        if (pool_frames) {
+            const hipError_t he = (hipError_t)c->stager_work(c->stager.jobs[job_frames], true);
+            if (he != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: frame upload: %s", hipGetErrorString(he));
+        } else {
+            int rc0 = upload_planes(c, c->d_in, frames, row_bytes, b.height, row_stride, frame_stride, B, c->stream);
+            if (rc0) return rc0;
+        }
         src = c->d_in;
         row_stride = row_bytes;
         frame_stride = (size_t)row_bytes * b.height;
     }
-    // (the helper queues the depth copy behind the frames' copies; it is told to once nothing records a graph any more)
-    if (depth_by_helper && frames_host) HIP_TRY(c, hipEventRecord(c->ev_frames, c->stream));
     const uint8_t *rsrc = right;
     if (right_on_host) {
         uint8_t *dst = c->d_in + frames_bytes;  // second half of the staging area on the device
@@ -581,7 +628,7 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     // would share the link and delay the frames, which everything waits for).  Ordinary memory: the copy call
     // keeps this thread busy, so it is made after the first part of the chain has been launched.
     const bool depth_early = depth_from_host && !stage_depth;
-    const bool depth_late = depth_from_host && !depth_early && !depth_by_helper;
+    const bool depth_late = depth_from_host && !depth_early && !pool_depth;
     auto upload_depth = [&]() -> int {
         if (frames_from_host) {
             HIP_TRY(c, hipEventRecord(c->ev_frames, c->stream));
@@ -735,16 +782,18 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             }
             c->graph_key = key;
         }
-        helper.release(false);
+        if (pool_depth) (void)c->stager_send(c->stager.jobs[job_depth], false);
         HIP_TRY(c, hipGraphLaunch(c->graph_exec, c->stream));
     } else {
-        helper.release(false);
+        // (chunks of the depth plane that the helpers have packed by now go on their way before the launches)
+        if (pool_depth) (void)c->stager_send(c->stager.jobs[job_depth], false);
         chain_front();
     }
     if (depth_late && (rc = upload_depth())) return rc;
-    if (depth_by_helper) {
-        const hipError_t he = (hipError_t)helper.finish();
+    if (pool_depth) {
+        const hipError_t he = (hipError_t)c->stager_work(c->stager.jobs[job_depth], true);
         if (he != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: depth upload: %s", hipGetErrorString(he));
+        HIP_TRY(c, hipEventRecord(c->ev_depth, c->copy_stream));
     }
     if (depth_from_host) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_depth, 0));
     if (c->use_graph) {

@@ -1,6 +1,7 @@
 // Device-side state of one vo_ctx.
 #pragma once
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -161,23 +162,45 @@ struct vo_ctx {
     void *h_stage = nullptr;
     size_t h_stage_bytes = 0;
 
-    // Helper thread of the single-stream path: packs a depth plane that arrives in ordinary host memory into the
-    // pinned staging area while the caller's thread stages the frame and launches the first kernels, then queues
-    // its DMA behind the frame's.  Started on first use.
-    struct DepthStager {
-        std::thread th;
-        std::mutex m;
-        std::condition_variable cv;
-        bool posted = false, go = false, cancel = false, issued = false, quit = false;
+    // Helper threads of the single-stream path.  A frame and a depth plane that arrive in ordinary host memory are
+    // packed into the pinned staging area before they are sent; one core packs at 15-20 GB/s, a third of what the
+    // link takes, so the pieces of a plane set are dealt out among the calling thread and up to three helpers
+    // (started on first use, asleep on the condition variable between frames).  The helpers only move bytes; the
+    // calling thread makes every HIP call: it queues the copy of a chunk (eight pieces) as soon as all pieces of
+    // the chunk are packed -- a copy call costs 10-20 us of host time, so they are few and large.  A job is one
+    // plane set; the jobs of a call are worked through in order (the frame first, then the depth plane, which
+    // nothing reads before the back-projection).
+    struct StageJob {
+        static constexpr size_t kPiece = 256u << 10;
+        static constexpr int kChunkPieces = 8;
+        static constexpr size_t kChunk = kPiece * kChunkPieces;
         const uint8_t *src = nullptr;
         uint8_t *stage = nullptr, *dst = nullptr;
-        size_t row_bytes = 0, row_stride = 0, plane_stride = 0;
-        int rows = 0, count = 0;
-        bool wait_frames = false;
-        int err = 0;  // hipError_t of the worker's calls
+        size_t row_bytes = 0, row_stride = 0, plane_stride = 0, total = 0;
+        int rows = 0, count = 0, n_pieces = 0, n_chunks = 0;
+        hipStream_t stream = nullptr;
+        std::atomic<int> next{0};                                   // next piece to take
+        std::atomic<int> packed[kStageMaxBytes / kChunk + 1] = {};  // packed pieces per chunk
+        int sent = 0;                                               // chunks whose copy is queued (calling thread only)
+        int err = 0;                                                // first hipError_t (calling thread only)
+    };
+    struct StagePool {
+        static constexpr int kMaxHelpers = 3;
+        std::thread th[kMaxHelpers];
+        int n_threads = 0;
+        std::mutex m;
+        std::condition_variable cv;
+        uint64_t epoch = 0;   // bumped for every posted set of jobs
+        int active = 0;       // helpers working on the current epoch
+        bool quit = false;
+        StageJob jobs[2];
+        int n_jobs = 0;
     } stager;
     void stager_loop();
     void stager_stop();
+    void stager_post(int n_jobs);        // jobs[0..n_jobs) are filled in: wake the helpers
+    int stager_send(StageJob &j, bool block);   // calling thread: queue the copies of the chunks that are packed (block: of all)
+    int stager_work(StageJob &j, bool caller);  // pack pieces of j until none is left; caller: and queue the copies
 
     static constexpr size_t kPinnedBytes = 1 << 20;
     size_t pinned_bytes = 0;  // max(kPinnedBytes, max_batch result records)
