@@ -947,7 +947,9 @@ void launch_frontend_levels(const OrbPlan &plan, int first_level, const uint8_t 
 
 constexpr int SEL_THREADS = 1024;
 
-__device__ __forceinline__ void bitonic_sort_lds(uint32_t *keys, int n_pow2)
+// Ascending bitonic sort of n_pow2 keys in LDS, any size: one compare-exchange per thread and step, a barrier
+// per stage.
+__device__ __forceinline__ void bitonic_sort_lds_any(uint32_t *keys, int n_pow2)
 {
     for (int k = 2; k <= n_pow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -962,6 +964,46 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *keys, int n_pow2)
             __syncthreads();
         }
     }
+}
+
+// Ascending bitonic sort of n_pow2 <= 2 * SEL_THREADS keys in LDS.  A thread keeps the keys at positions tid and
+// tid + SEL_THREADS in registers; exchanges at a distance below the wave size are lane shuffles, the distance
+// SEL_THREADS is inside the thread, and only the distances in between go through LDS with block barriers (10 of
+// the 55 stages of 1024 keys; a single frame's selection is a third sort, so the barriers were most of it).
+__device__ __forceinline__ void bitonic_sort_lds(uint32_t *keys, int n_pow2)
+{
+    const int i0 = threadIdx.x, i1 = threadIdx.x + SEL_THREADS;
+    const bool two = n_pow2 > SEL_THREADS;  // block-uniform
+    uint32_t v0 = i0 < n_pow2 ? keys[i0] : 0xffffffffu;
+    uint32_t v1 = two ? keys[i1] : 0xffffffffu;
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == SEL_THREADS) {  // only with two keys per thread, k = 2 * SEL_THREADS: ascending everywhere
+                const uint32_t lo = min(v0, v1), hi = max(v0, v1);
+                v0 = lo; v1 = hi;
+                continue;
+            }
+            uint32_t p0, p1 = 0;
+            if (j >= 64) {
+                __syncthreads();  // the previous stage's reads are done
+                if (i0 < n_pow2) keys[i0] = v0;
+                if (two) keys[i1] = v1;
+                __syncthreads();
+                p0 = i0 < n_pow2 ? keys[i0 ^ j] : v0;
+                if (two) p1 = keys[i1 ^ j];
+            } else {
+                p0 = __shfl_xor(v0, j);
+                if (two) p1 = __shfl_xor(v1, j);
+            }
+            const bool low = (i0 & j) == 0;  // (i1 & j) is the same: j < SEL_THREADS
+            v0 = (((i0 & k) == 0) == low) ? min(v0, p0) : max(v0, p0);
+            if (two) v1 = (((i1 & k) == 0) == low) ? min(v1, p1) : max(v1, p1);
+        }
+    }
+    __syncthreads();
+    if (i0 < n_pow2) keys[i0] = v0;
+    if (two) keys[i1] = v1;
+    __syncthreads();
 }
 
 // One block per frame.  reference src/feature_detector.cpp:62-68 sorts all
@@ -1064,7 +1106,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const uint32_t *__restri
     while (n_pow2 < K) n_pow2 <<= 1;
     for (int i = K + tid; i < n_pow2; i += SEL_THREADS) s_keys[i] = 0xffffffffu;
     __syncthreads();
-    if (n_pow2 > 1) bitonic_sort_lds(s_keys, n_pow2);
+    if (n_pow2 > 2 * SEL_THREADS)
+        bitonic_sort_lds_any(s_keys, n_pow2);
+    else if (n_pow2 > 1)
+        bitonic_sort_lds(s_keys, n_pow2);
 
     // border filter + ordered compaction
     const int n_sel = min(K, max_features);
