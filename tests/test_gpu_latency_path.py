@@ -240,3 +240,41 @@ def test_depth16_gray_input_equals_float_depth(ctx, oracle):
             if r["pnp_success"]:
                 assert np.array_equal(l16[b][1], r["inliers"])
                 assert np.abs(r16["rvec"][b] - r["rvec"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("F", [2, 5])
+def test_padded_host_planes_in_ordinary_memory(ctx, F):
+    """Frames and depth planes handed over as padded rows and padded planes of ordinary host memory (the row-by-row
+    packing of the staging pool: pieces and chunks end in the middle of rows and planes), several frames per launch:
+    same results as from contiguous arrays."""
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    seqs = [synth.make_sequence(cam, 2 * F, seed=4700, channels=4)]
+    ref = _run(ctx, cam, seqs, F, 2, 0, packed=False, graph=False)
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=F, max_features=600,
+                        fast_threshold=20, camera=K, orb_levels=0)
+    ctx.batch_set_packed_output(False)
+    ctx.batch_set_graph(False)
+    row, drow = cam.width * 4 + 52, cam.width + 13            # bytes / elements
+    plane, dplane = row * cam.height + 1000, drow * cam.height + 77
+    rng = np.random.default_rng(3)
+    out = []
+    for nb in range(2):
+        fb = rng.integers(0, 256, F * plane, dtype=np.uint8)   # garbage in the padding
+        db = rng.random(F * dplane, dtype=np.float32) * 9000.0
+        for f in range(F):
+            v = fb[f * plane:f * plane + row * cam.height].reshape(cam.height, row)
+            v[:, :cam.width * 4] = seqs[0]["frames"][nb * F + f].reshape(cam.height, cam.width * 4)
+            d = db[f * dplane:f * dplane + drow * cam.height].reshape(cam.height, drow)
+            d[:, :cam.width] = seqs[0]["depth"][nb * F + f]
+        ctx.batch_submit_ptr(fb.ctypes.data, row, plane, db.ctypes.data, drow, dplane)
+        res = ctx.batch_wait()
+        for b in range(F):
+            k, d = ctx.batch_features(b)
+            m, _ = ctx.batch_matches(b, 0)
+            t, _ = ctx.batch_matches(b, 1)
+            v, p3 = ctx.batch_matches(b, 2)
+            out.append({"kps": k, "desc": d, "matches": m, "tracked": t, "valid": v, "pts3": p3,
+                        "inliers": ctx.batch_inliers(b) if res["pnp_success"][b] else np.zeros(0, np.int32),
+                        "result": res[b].copy()})
+    _same(out, ref)
