@@ -41,13 +41,19 @@ def main(path, frames_per_launch, out, sq_path=None, kstats_path=None):
     for stage, frag in (("frontend_fast_nms_blur", "k_frontendILi4E"), ("pyramid_resize", "k_resize_exact"),
                         ("frontend_upper_levels", "k_frontend_levels"), ("brief", "k_brief_steered"),
                         ("knn2", "k_knn2"), ("select_topn_rank", "k_orb_select"), ("select_topn_finish", "k_orb_finish")):
-        d = find(frag)
-        if not d or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        # (a stage may be several kernels: the ranking kernel runs as two instantiations, one per block size)
+        ds = [d for name, d in kb.items() if frag in name and "FETCH_SIZE" in d and "WRITE_SIZE" in d]
+        if not ds:
             continue
-        n = max(1, d["FETCH_SIZE"][1] // max(1, steps))   # launches per batch (the averages are per launch)
-        fetch, write = 2 * d["FETCH_SIZE"][0] * 1024 * n, d["WRITE_SIZE"][0] * 1024 * n
+        fetch = write = 0.0
+        launches = 0
+        for d in ds:
+            n = max(1, d["FETCH_SIZE"][1] // max(1, steps))   # launches per batch (the averages are per launch)
+            fetch += 2 * d["FETCH_SIZE"][0] * 1024 * n
+            write += d["WRITE_SIZE"][0] * 1024 * n
+            launches += n
         stages[stage] = {"bytes": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
-                         "note": f"{n} launch(es) per batch; 2 x FETCH_SIZE + WRITE_SIZE"}
+                         "note": f"{launches} launch(es) per batch; 2 x FETCH_SIZE + WRITE_SIZE"}
     # vector-ALU occupancy of the same kernels: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, so
     # busy = 4 * count / (1024 SIMDs * 2.4 GHz * average kernel duration from the kernel trace)
     if sq_path and kstats_path:

@@ -183,6 +183,10 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
 
 constexpr int OS_THREADS = 1024;
 constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level
+// Levels with a small quota go to blocks a quarter of the size with a third of the LDS: eight of them per CU instead
+// of two, and barriers among four waves instead of sixteen (ranking of 512 HD720 frames 0.30 -> 0.26 ms).  512-thread
+// blocks for the levels in between were measured and change nothing.
+constexpr int OS_THREADS_S = 256, OS_K1CAP_S = 1536, OS_LCAP_S = 768;
 
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
@@ -282,7 +286,9 @@ __device__ unsigned long long g_os_stamps[8 * 32 * 16];
 // where retainBest(n) keeps every keypoint whose response is >= the n-th
 // largest (all boundary ties survive).  OpenCV leaves the survivors in
 // nth_element order (unspecified); here they are written in raster order.
-__global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, const uint8_t *__restrict__ pyr,
+template <int OS_THREADS, int OS_K1CAP, int OS_LCAP>
+__global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, int first_level,
+                                                          const uint8_t *__restrict__ pyr,
                                                           const uint32_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ tile_count,
                                                           uint32_t *__restrict__ flat,
@@ -292,15 +298,15 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     __shared__ uint32_t s_buf[2 * OS_K1CAP];
     __shared__ uint32_t s_scan[OS_THREADS];
     uint32_t *const s_ras = s_buf, *const s_key = s_buf + OS_K1CAP;
-    __shared__ __attribute__((aligned(16))) uint32_t s_oras[kOrbLevelCap];
-    __shared__ uint32_t s_okey[kOrbLevelCap];
+    __shared__ __attribute__((aligned(16))) uint32_t s_oras[OS_LCAP];
+    __shared__ uint32_t s_okey[OS_LCAP];
     __shared__ uint32_t s_hist[256];
     __shared__ int s_cut, s_n1, s_n2, s_remaining;
     __shared__ uint32_t s_prefix;
 
     // grid x = frame, y = level: consecutive blocks go to consecutive XCDs, so every XCD sees all levels
     // (with the level in x each XCD would serve a single level and the level-0 one would finish last)
-    const int f = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
+    const int f = blockIdx.x, l = first_level + (int)blockIdx.y, tid = threadIdx.x;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
     OS_STAMP(0);
@@ -401,11 +407,11 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     for (int i = tid; i < K1; i += OS_THREADS) {
         if (s_key[i] >= threshold) {
             const int slot = atomicAdd(&s_n2, 1);
-            if (slot < kOrbLevelCap) { s_oras[slot] = s_ras[i]; s_okey[slot] = s_key[i]; }
+            if (slot < OS_LCAP) { s_oras[slot] = s_ras[i]; s_okey[slot] = s_key[i]; }
         }
     }
     __syncthreads();
-    const int K2 = min(s_n2, kOrbLevelCap);
+    const int K2 = min(s_n2, OS_LCAP);
     OS_STAMP(7);
     // raster order by counting: the rank of a survivor is the number of survivors with a smaller raster index
     // (all distinct); every lane of a wave reads the same four entries per step (LDS broadcast)
@@ -768,8 +774,22 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
                        const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
                        hipStream_t s)
 {
-    hipLaunchKernelGGL(k_orb_select, dim3(batch, plan.nlevels), dim3(OS_THREADS), 0, s, plan, batch, pyr, cand,
-                       tile_count, flat, lvl_ras, lvl_resp, lvl_n);
+    // Quotas fall with the level: levels [0, sm) need the large variant, [sm, n) fit the small one (same margins for
+    // boundary ties as orb_plan_fits: 256 at the Harris cut, 512 at the FAST-score cut)
+    int sm = plan.nlevels;
+    while (sm > 0 && plan.lv[sm - 1].quota <= OS_LCAP_S - 256 && 2 * plan.lv[sm - 1].quota + 512 <= OS_K1CAP_S &&
+           plan.lv[sm - 1].tiles <= 2 * OS_K1CAP_S)
+        sm--;
+    // (VO_OS_SMALL_FROM=n: levels below n keep the large variant, for comparisons)
+    static const int force = getenv("VO_OS_SMALL_FROM") ? atoi(getenv("VO_OS_SMALL_FROM")) : -1;
+    if (force >= 0) sm = std::max(sm, std::min(force, plan.nlevels));
+    if (sm > 0)
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, kOrbLevelCap>), dim3(batch, sm), dim3(OS_THREADS), 0, s,
+                           plan, batch, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp, lvl_n);
+    if (plan.nlevels > sm)
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS_S, OS_K1CAP_S, OS_LCAP_S>), dim3(batch, plan.nlevels - sm),
+                           dim3(OS_THREADS_S), 0, s, plan, batch, sm, pyr, cand, tile_count, flat, lvl_ras, lvl_resp,
+                           lvl_n);
 }
 
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
