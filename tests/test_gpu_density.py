@@ -73,3 +73,31 @@ def test_orb_level_quota_limit(big_ctx, oracle, noise):
     with pytest.raises(capi.VoError) as e:
         big_ctx.detect_orb(img, nfeatures=4000, scale_factor=2.0, nlevels=3, fast_threshold=20, cap=N)
     assert e.value.code == capi.VO_ERR_UNSUPPORTED and "1792" in str(e.value)
+
+
+def test_orb_tie_class_beyond_the_small_ranking_lists(big_ctx, oracle):
+    """A regular pattern of equal squares: at level 1 all 2808 corners inside the border share one FAST score, so the
+    cut at 2 x quota = 724 keeps all of them -- more than the lists of the 256-thread ranking blocks hold (1536).  Those
+    blocks must hand the level to the full-size variant; the result is the oracle's, also when only some frames of
+    a batch are affected."""
+    w, h = 1280, 720
+    img = np.full((h, w), 60, np.uint8)
+    for y in range(8, h - 9, 28):
+        for x in range(8, w - 9, 28):
+            img[y:y + 9, x:x + 9] = 200
+    kr, dr, lv, _ = oracle.orb_detect(img, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20, pyramid=True)
+    c = oracle.fast(lv[1], 20)
+    inside = (c["x"] >= 31) & (c["x"] < lv[1].shape[1] - 31) & (c["y"] >= 31) & (c["y"] < lv[1].shape[0] - 31)
+    assert 1536 < inside.sum() <= 4096 and len(np.unique(c["response"][inside])) == 1   # the premise
+    k, d = big_ctx.detect_orb(img, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20, cap=N)
+    assert len(kr) > 1000 and np.array_equal(k, kr) and np.array_equal(d, dr)
+    rng = np.random.default_rng(9)
+    other = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ko, do = oracle.orb_detect(other, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20)
+    big_ctx.batch_configure(w, h, 1, n_streams=1, frames_per_stream=2, max_features=2000, fast_threshold=20,
+                            orb_levels=8)
+    big_ctx.batch_submit(np.stack([other, img]), None)
+    big_ctx.batch_wait()
+    for f, (a, b) in enumerate(((ko, do), (kr, dr))):
+        kk, dd = big_ctx.batch_features(f)
+        assert np.array_equal(kk, a[:2000]) and np.array_equal(dd, b[:2000]), f

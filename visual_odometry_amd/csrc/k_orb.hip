@@ -183,10 +183,13 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
 
 constexpr int OS_THREADS = 1024;
 constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level
-// Levels with a small quota go to blocks a quarter of the size with a third of the LDS: eight of them per CU instead
-// of two, and barriers among four waves instead of sixteen (ranking of 512 HD720 frames 0.30 -> 0.26 ms).  512-thread
-// blocks for the levels in between were measured and change nothing.
+// Levels with a small quota (all eight at 2000 key points) go to blocks a quarter of the size with a third of the
+// LDS: eight of them per CU instead of two, and barriers among four waves instead of sixteen (ranking of 512 HD720
+// frames 0.30 -> 0.23 ms).  A block of the small variant whose level has more boundary ties than its lists hold
+// (a score class of hundreds of equal corners at the cut: dense, repetitive texture) marks the level and leaves; a
+// second pass of the large variant takes the marked levels and nothing else.
 constexpr int OS_THREADS_S = 256, OS_K1CAP_S = 1536, OS_LCAP_S = 768;
+constexpr int kOrbLevelRedo = -1;  // lvl_n of a level the small variant has left to the large one
 
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
@@ -287,7 +290,7 @@ __device__ unsigned long long g_os_stamps[8 * 32 * 16];
 // largest (all boundary ties survive).  OpenCV leaves the survivors in
 // nth_element order (unspecified); here they are written in raster order.
 template <int OS_THREADS, int OS_K1CAP, int OS_LCAP>
-__global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, int first_level,
+__global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int batch, int first_level, int redo_only,
                                                           const uint8_t *__restrict__ pyr,
                                                           const uint32_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ tile_count,
@@ -307,6 +310,8 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     // grid x = frame, y = level: consecutive blocks go to consecutive XCDs, so every XCD sees all levels
     // (with the level in x each XCD would serve a single level and the level-0 one would finish last)
     const int f = blockIdx.x, l = first_level + (int)blockIdx.y, tid = threadIdx.x;
+    constexpr bool kSmall = OS_K1CAP < 4096;  // this variant may leave a level to the large one
+    if (redo_only && lvl_n[f * plan.nlevels + l] != kOrbLevelRedo) return;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
     OS_STAMP(0);
@@ -360,6 +365,10 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
             }
         }
     __syncthreads();
+    if (kSmall && s_n1 > OS_K1CAP) {  // (block-uniform)
+        if (tid == 0) lvl_n[f * plan.nlevels + l] = kOrbLevelRedo;
+        return;
+    }
     const int K1 = min(s_n1, OS_K1CAP);
 
     OS_STAMP(4);
@@ -411,6 +420,10 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
         }
     }
     __syncthreads();
+    if (kSmall && s_n2 > OS_LCAP) {
+        if (tid == 0) lvl_n[f * plan.nlevels + l] = kOrbLevelRedo;
+        return;
+    }
     const int K2 = min(s_n2, OS_LCAP);
     OS_STAMP(7);
     // raster order by counting: the rank of a survivor is the number of survivors with a smaller raster index
@@ -785,11 +798,15 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
     if (force >= 0) sm = std::max(sm, std::min(force, plan.nlevels));
     if (sm > 0)
         hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, kOrbLevelCap>), dim3(batch, sm), dim3(OS_THREADS), 0, s,
-                           plan, batch, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp, lvl_n);
-    if (plan.nlevels > sm)
+                           plan, batch, 0, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp, lvl_n);
+    if (plan.nlevels > sm) {
         hipLaunchKernelGGL((k_orb_select<OS_THREADS_S, OS_K1CAP_S, OS_LCAP_S>), dim3(batch, plan.nlevels - sm),
-                           dim3(OS_THREADS_S), 0, s, plan, batch, sm, pyr, cand, tile_count, flat, lvl_ras, lvl_resp,
+                           dim3(OS_THREADS_S), 0, s, plan, batch, sm, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp,
                            lvl_n);
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, kOrbLevelCap>), dim3(batch, plan.nlevels - sm),
+                           dim3(OS_THREADS), 0, s, plan, batch, sm, /*redo_only=*/1, pyr, cand, tile_count, flat,
+                           lvl_ras, lvl_resp, lvl_n);
+    }
 }
 
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,
