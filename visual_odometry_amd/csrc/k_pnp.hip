@@ -37,6 +37,7 @@ constexpr int PR_WIN = PR_CHUNK * 5 + 96;         // RNG words examined per roun
 constexpr int PR_NRED = 45;                       // 36 JtJ + 6 JtErr + |err|^2 (pose); 36 + 8 + 1 (homography)
 constexpr int kPnpSpecMax = 128;                  // hypotheses per frame the second launch can hold
 constexpr int kPnpItemsPerFrame = 16;             // work items (runs of up to PR_CHUNK hypotheses) per frame
+constexpr int PR_WIN_ALL = kPnpSpecMax * 5 + 128;  // RNG words examined at once when a frame is handed over
 
 // ---------------------------------------------------------------------
 // small dense algebra, register resident (all indices static after unrolling)
@@ -681,6 +682,9 @@ struct PrShared {
     int start[PR_CHUNK];
     uint16_t r[PR_WIN];
     uint8_t cons[PR_WIN];
+    uint16_t r_all[PR_WIN_ALL];   // the same for all hypotheses of a frame that is handed over
+    uint8_t cons_all[PR_WIN_ALL];
+    int item_start[kPnpItemsPerFrame], item_first[kPnpItemsPerFrame], item_count[kPnpItemsPerFrame], n_new_items;
     int wave_tot[PR_WAVES];
     int nchunk, per_wave, iter, niters, max_good, done;
     long long pos;
@@ -698,12 +702,12 @@ struct PrShared {
     double wmax[PR_WAVES];
 };
 
-__device__ __forceinline__ int draw_subset5(const uint16_t *r, int o, int (&idx)[5])
+__device__ __forceinline__ int draw_subset5(const uint16_t *r, int o, int (&idx)[5], int win = PR_WIN)
 {
     int p = o;
     for (int i = 0; i < 5; i++) {
         for (;;) {
-            if (p >= PR_WIN) return 0;
+            if (p >= win) return 0;
             const int v = r[p++];
             bool dup = false;
             for (int j = 0; j < i; j++) dup = dup || (idx[j] == v);
@@ -1921,14 +1925,53 @@ __device__ __forceinline__ bool pnp_publish_items(PrShared &S, const PnpArgs &a,
     const int want_all = S.niters - S.iter;
     int covered = 0, n_items = 0;
     PnpItem *mine = a.items + (size_t)b * kPnpItemsPerFrame;
+    // One window for all of them (the claimers chain their own ten again from the item's position): every offset
+    // simulated as the start of a subset draw by all threads, then one lane walks the chain and notes where every
+    // PR_CHUNK-th hypothesis starts.  Chaining item by item cost a handed-over frame 150 k - 300 k cycles before
+    // its first item was on offer.
     while (covered < want_all && n_items < kPnpItemsPerFrame) {
-        const long long pos0 = S.pos;
-        pnp_chain_round(S, n, a.rng_raw, a.rng_len, min(PR_CHUNK, want_all - covered));
-        const int nc = S.nchunk;
-        if (nc == 0) break;
-        if (tid == 0) mine[n_items] = PnpItem{pos0, covered, nc};
-        covered += nc;
-        n_items++;
+        const long long pos = S.pos;
+        for (int k = tid; k < PR_WIN_ALL; k += PR_THREADS) {
+            const long long w = pos + k;
+            S.r_all[k] = w < a.rng_len ? (uint16_t)(a.rng_raw[w] % (uint32_t)n) : (uint16_t)0;
+        }
+        __syncthreads();
+        for (int o = tid; o < PR_WIN_ALL; o += PR_THREADS) {
+            int idx[5];
+            int cons = draw_subset5(S.r_all, o, idx, PR_WIN_ALL);
+            if (pos + o + cons > a.rng_len) cons = 0;
+            S.cons_all[o] = (uint8_t)cons;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int want = want_all - covered, room = kPnpItemsPerFrame - n_items;
+            int w = 0, nc = 0, ni = 0;
+            while (nc < want && w < PR_WIN_ALL && S.cons_all[w] != 0) {
+                const int c = S.cons_all[w];
+                // a new item after PR_CHUNK hypotheses, or when this one would end outside the window of PR_WIN
+                // words in which the item's claimer chains them again (many redraws: very few points)
+                if (ni == 0 || S.item_count[ni - 1] == PR_CHUNK || w + c - S.item_start[ni - 1] > PR_WIN) {
+                    if (ni == room) break;
+                    S.item_start[ni] = w;
+                    S.item_first[ni] = nc;
+                    S.item_count[ni] = 0;
+                    ni++;
+                }
+                S.item_count[ni - 1]++;
+                nc++;
+                w += c;
+            }
+            for (int j = 0; j < ni; j++)
+                mine[n_items + j] = PnpItem{pos + S.item_start[j], covered + S.item_first[j], S.item_count[j]};
+            S.nchunk = nc;
+            S.n_new_items = ni;
+            S.pos = pos + w;
+        }
+        __syncthreads();
+        if (S.nchunk == 0) break;
+        covered += S.nchunk;
+        n_items += S.n_new_items;
+        __syncthreads();  // (S.nchunk is written again in the next pass)
     }
     if (n_items == 0) return false;
     if (tid == 0) {
