@@ -195,12 +195,13 @@ static void svd12_onesided(const double *Gcm, int rows, double *w, double *Vt)
  * n <= 12) by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT
  * system of the pose refinement (n = 12) and the normalised DLT of the homography (n = 9) have one eigenvalue far
  * below the others (the solution, at the noise level; exactly zero for four points), so the iteration converges
- * in a few steps; what cv::SVD would return as the last row of V^T, up to sign. */
+ * in a few steps; what cv::SVD would return as the last row of V^T, up to sign.  Divisions by a pivot or by the
+ * norm are multiplications by its reciprocal (one division per pivot and per step). */
 static void smallest_eigvec_n(const double *A, int n, double *x)
 {
     /* L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
      * number: for inverse iteration that only steepens the amplification of the wanted direction */
-    double Lf[144], D[12];
+    double Lf[144], D[12], invD[12];
     double dmax = 0;
     for (int i = 0; i < n; i++) dmax = fmax(dmax, fabs(A[i * n + i]));
     const double tiny = dmax * 1e-30 + 1e-300;
@@ -209,10 +210,11 @@ static void smallest_eigvec_n(const double *A, int n, double *x)
         for (int k = 0; k < j; k++) d -= Lf[j * n + k] * Lf[j * n + k] * D[k];
         if (!(d > tiny)) d = tiny;
         D[j] = d;
+        invD[j] = 1.0 / d;
         for (int i = j + 1; i < n; i++) {
             double v = A[i * n + j];
             for (int k = 0; k < j; k++) v -= Lf[i * n + k] * Lf[j * n + k] * D[k];
-            Lf[i * n + j] = v / d;
+            Lf[i * n + j] = v * invD[j];
         }
     }
     for (int i = 0; i < n; i++) x[i] = 1.0 / sqrt((double)n);
@@ -223,7 +225,7 @@ static void smallest_eigvec_n(const double *A, int n, double *x)
             for (int k = 0; k < i; k++) v -= Lf[i * n + k] * y[k];
             y[i] = v;
         }
-        for (int i = 0; i < n; i++) y[i] /= D[i];
+        for (int i = 0; i < n; i++) y[i] *= invD[i];
         for (int i = n - 1; i >= 0; i--) {     /* L^T y = z */
             double v = y[i];
             for (int k = i + 1; k < n; k++) v -= Lf[k * n + i] * y[k];
@@ -233,7 +235,8 @@ static void smallest_eigvec_n(const double *A, int n, double *x)
         for (int i = 0; i < n; i++) nrm += y[i] * y[i];
         nrm = sqrt(nrm);
         if (!(nrm > 0) || !isfinite(nrm)) break;
-        for (int i = 0; i < n; i++) x[i] = y[i] / nrm;
+        const double inrm = 1.0 / nrm;
+        for (int i = 0; i < n; i++) x[i] = y[i] * inrm;
     }
 }
 static void smallest_eigvec12(const double *A, double *x) { smallest_eigvec_n(A, 12, x); }

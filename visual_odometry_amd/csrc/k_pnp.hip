@@ -405,11 +405,9 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
         for (int r = 0; r < 11; r++) {
             const int y = col ? rr_partner(gl, r) : gl;
             const int src = base + y;
-            double pg[ROWS], pv[12];
+            double pg[ROWS];
 #pragma unroll
             for (int i = 0; i < ROWS; i++) pg[i] = __shfl(g[i], src);
-#pragma unroll
-            for (int i = 0; i < 12; i++) pv[i] = __shfl(v[i], src);
             const bool am_p = gl < y;
             double so = 0, gamma = 0;
 #pragma unroll
@@ -421,6 +419,11 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
             const double alpha = am_p ? so : sp, beta = am_p ? sp : so;
             const bool skip = !col || fabs(gamma) <= eps * sqrt(alpha * beta) || fabs(gamma) <= 1e-26 * frob;
             if (!skip) {
+                // (both lanes of a pair see the same alpha, beta and gamma -- a product does not depend on the order
+                // of its factors -- so they are here together and can exchange their columns of V)
+                double pv[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) pv[i] = __shfl(v[i], src);
                 rotated = true;
                 const double zeta = (beta - alpha) / (2 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
@@ -799,13 +802,15 @@ __device__ void block_reduce(PrShared &S, double (&v)[NV])
 // by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
 // the pose refinement (N = 12) and the normalised DLT of the homography (N = 9) have one eigenvalue far below the
 // others (the solution, at the noise level; exactly zero for four points), so the iteration converges in a few
-// steps.  One lane, everything unrolled into registers; a tenth of the cycles of a Jacobi decomposition.
+// steps.  One lane, everything unrolled into registers; a tenth of the cycles of a Jacobi decomposition.  Divisions
+// by a pivot or by the norm are multiplications by its reciprocal: one division per pivot and per step instead of
+// 66 + 24 per step (a double-precision division is a dozen instructions).
 template <int N>
 __device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
 {
     // L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
     // number: for inverse iteration that only steepens the amplification of the wanted direction
-    double Lf[N * N], D[N];
+    double Lf[N * N], D[N], invD[N];
     double dmax = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) dmax = fmax(dmax, fabs(A[i * N + i]));
@@ -817,12 +822,13 @@ __device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
         for (int k = 0; k < j; k++) d -= Lf[j * N + k] * Lf[j * N + k] * D[k];
         if (!(d > tiny)) d = tiny;
         D[j] = d;
+        invD[j] = 1.0 / d;
 #pragma unroll
         for (int i = j + 1; i < N; i++) {
             double v = A[i * N + j];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= Lf[i * N + k] * Lf[j * N + k] * D[k];
-            Lf[i * N + j] = v / d;
+            Lf[i * N + j] = v * invD[j];
         }
     }
 #pragma unroll
@@ -837,7 +843,7 @@ __device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
             y[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < N; i++) y[i] /= D[i];
+        for (int i = 0; i < N; i++) y[i] *= invD[i];
 #pragma unroll
         for (int i = N - 1; i >= 0; i--) {     // L^T y = z
             double v = y[i];
@@ -850,8 +856,9 @@ __device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
         for (int i = 0; i < N; i++) nrm += y[i] * y[i];
         nrm = sqrt(nrm);
         if (!(nrm > 0) || !isfinite(nrm)) break;
+        const double inrm = 1.0 / nrm;
 #pragma unroll
-        for (int i = 0; i < N; i++) x[i] = y[i] / nrm;
+        for (int i = 0; i < N; i++) x[i] = y[i] * inrm;
     }
 }
 __device__ __noinline__ void smallest_eigvec12(const double *A, double *x) { smallest_eigvec<12>(A, x); }
