@@ -429,12 +429,14 @@ __global__ __launch_bounds__(FR_THREADS) void k_f_ransac(const vo_match *__restr
             }
             __syncthreads();
             int at = 0;
+            // (only the first `room` visited offsets are used: a short round needs fewer levels)
+            const int levels = 32 - __builtin_clz(room);
 #pragma unroll 1
-            for (int lv = 0; lv < 7; lv++) {
+            for (int lv = 0; lv < levels; lv++) {
                 const uint16_t *J = S.jump[lv & 1];
                 uint16_t *Jn = S.jump[(lv + 1) & 1];
                 if (tid < FR_VISIT && ((tid >> lv) & 1)) at = J[at];
-                if (lv < 6)
+                if (lv < levels - 1)
                     for (int o = tid; o <= win; o += FR_THREADS) Jn[o] = J[J[o]];
                 __syncthreads();
             }
