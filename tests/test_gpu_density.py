@@ -101,3 +101,22 @@ def test_orb_tie_class_beyond_the_small_ranking_lists(big_ctx, oracle):
     for f, (a, b) in enumerate(((ko, do), (kr, dr))):
         kk, dd = big_ctx.batch_features(f)
         assert np.array_equal(kk, a[:2000]) and np.array_equal(dd, b[:2000]), f
+
+
+def test_largest_frame(oracle):
+    """4096 x 4096 (2^24 pixels, the largest frame the library takes; corner keys hold y and x in 12 bits each):
+    both detectors against the oracle, with key points in the far corner of the frame."""
+    from visual_odometry_amd import capi
+    w = h = 4096
+    rng = np.random.default_rng(4096)
+    # blocks of 4 x 4 equal pixels with some noise on top: corners at every scale of the pyramid
+    img = np.kron(rng.integers(0, 256, (h // 4, w // 4), dtype=np.uint8), np.ones((4, 4), np.uint8))
+    img = np.clip(img.astype(np.int16) + rng.integers(-6, 7, (h, w)), 0, 255).astype(np.uint8)
+    with capi.Context(device=0, max_width=w, max_height=h, max_features=3000, max_batch=1) as c:
+        k, d = c.detect(img, 2000, 20)
+        kr, dr = oracle.detect(img, 2000, 20)
+        assert len(kr) > 1800 and np.array_equal(k, kr) and np.array_equal(d, dr)
+        k, d = c.detect_orb(img, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20, cap=3000)
+        kr, dr = oracle.orb_detect(img, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20)
+        assert len(kr) >= 2000 and np.array_equal(k, kr[:3000]) and np.array_equal(d, dr[:3000])
+        assert ((kr["x"] > 3900) & (kr["y"] > 3900)).any()
