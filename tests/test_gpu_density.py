@@ -63,16 +63,18 @@ def test_noise_frames_one_batched_launch(big_ctx, oracle, noise, levels):
 
 def test_orb_level_quota_limit(big_ctx, oracle, noise):
     """cv::ORB::create(nfeatures, scale, levels) takes any numbers; the full detector here keeps a level's
-    candidates in LDS and takes at most 1792 key points from one level.  3000 / 2.0 / 3 asks level 0 for 1714 and
-    works; 4000 / 2.0 / 3 asks for 2286 and is refused with a message that says so."""
+    candidates in LDS and takes at most 3840 key points from one level.  3000 / 2.0 / 3 asks level 0 for 1714 (the
+    ordinary ranking variant), 4000 / 2.0 / 3 for 2286 and 6000 / 1.5 / 4 for 2492 (the largest variant); 6000 / 2.0 / 2
+    asks for 4000 and is refused with a message that says so."""
     from visual_odometry_amd import capi
     img = noise[1][:720, :1280]
-    k, d = big_ctx.detect_orb(img, nfeatures=3000, scale_factor=2.0, nlevels=3, fast_threshold=20, cap=N)
-    kr, dr = oracle.orb_detect(img, nfeatures=3000, scale_factor=2.0, nlevels=3, fast_threshold=20)
-    assert len(kr) >= 3000 and np.array_equal(k, kr[:N]) and np.array_equal(d, dr[:N])
+    for nf, sc, nl in ((3000, 2.0, 3), (4000, 2.0, 3), (6000, 1.5, 4)):
+        k, d = big_ctx.detect_orb(img, nfeatures=nf, scale_factor=sc, nlevels=nl, fast_threshold=20, cap=N)
+        kr, dr = oracle.orb_detect(img, nfeatures=nf, scale_factor=sc, nlevels=nl, fast_threshold=20)
+        assert len(kr) >= min(nf, N) and np.array_equal(k, kr[:N]) and np.array_equal(d, dr[:N]), (nf, sc, nl)
     with pytest.raises(capi.VoError) as e:
-        big_ctx.detect_orb(img, nfeatures=4000, scale_factor=2.0, nlevels=3, fast_threshold=20, cap=N)
-    assert e.value.code == capi.VO_ERR_UNSUPPORTED and "1792" in str(e.value)
+        big_ctx.detect_orb(img, nfeatures=6000, scale_factor=2.0, nlevels=2, fast_threshold=20, cap=N)
+    assert e.value.code == capi.VO_ERR_UNSUPPORTED and "3840" in str(e.value)
 
 
 def test_orb_tie_class_beyond_the_small_ranking_lists(big_ctx, oracle):

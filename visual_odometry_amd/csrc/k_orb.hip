@@ -182,14 +182,18 @@ __global__ __launch_bounds__(RZ_THREADS) void k_resize_exact(PlaneBatch src, int
 // ------------------------------------------------- per-level keypoint ranking
 
 constexpr int OS_THREADS = 1024;
-constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level
+constexpr int OS_K1CAP = 4096;  // candidates that can enter the Harris ranking of one level (ordinary variant)
+constexpr int OS_LCAP = 2048;   // survivors of one level (ordinary variant)
+// the variant for quotas beyond the ordinary one's (100 KB of LDS, one block per CU), also the one that takes over
+// levels whose tied classes overflow a smaller variant's lists
+constexpr int OS_K1CAP_XL = 8192, OS_LCAP_XL = kOrbLevelCap;
 // Levels with a small quota (all eight at 2000 key points) go to blocks a quarter of the size with a third of the
 // LDS: eight of them per CU instead of two, and barriers among four waves instead of sixteen (ranking of 512 HD720
-// frames 0.30 -> 0.23 ms).  A block of the small variant whose level has more boundary ties than its lists hold
-// (a score class of hundreds of equal corners at the cut: dense, repetitive texture) marks the level and leaves; a
-// second pass of the large variant takes the marked levels and nothing else.
+// frames 0.30 -> 0.23 ms).  A block of the small or the ordinary variant whose level has more boundary ties than its
+// lists hold (a score class of hundreds of equal corners at the cut: dense, repetitive texture) marks the level and
+// leaves; a second pass of the largest variant takes the marked levels and nothing else.
 constexpr int OS_THREADS_S = 256, OS_K1CAP_S = 1536, OS_LCAP_S = 768;
-constexpr int kOrbLevelRedo = -1;  // lvl_n of a level the small variant has left to the large one
+constexpr int kOrbLevelRedo = -1;  // lvl_n of a level a smaller variant has left to the largest one
 
 typedef short ss2 __attribute__((ext_vector_type(2)));
 
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(OS_THREADS) void k_orb_select(OrbPlan plan, int bat
     // grid x = frame, y = level: consecutive blocks go to consecutive XCDs, so every XCD sees all levels
     // (with the level in x each XCD would serve a single level and the level-0 one would finish last)
     const int f = blockIdx.x, l = first_level + (int)blockIdx.y, tid = threadIdx.x;
-    constexpr bool kSmall = OS_K1CAP < 4096;  // this variant may leave a level to the large one
+    constexpr bool kSmall = OS_K1CAP < OS_K1CAP_XL;  // this variant may leave a level to the largest one
     if (redo_only && lvl_n[f * plan.nlevels + l] != kOrbLevelRedo) return;
     const OrbLevel L = plan.lv[l];
     const int w = L.w, h = L.h, quota = L.quota, border = kFBorder;
@@ -711,9 +715,9 @@ bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures,
         } else {
             L.quota = nfeatures - sum > 0 ? nfeatures - sum : 0;
         }
-        if (L.quota > kOrbLevelCap - 256 || 2 * L.quota + 512 > OS_K1CAP) return false;
+        if (L.quota > OS_LCAP_XL - 256 || 2 * L.quota + 512 > OS_K1CAP_XL) return false;
         L.tiles = tiles_of(L.w, L.h);
-        if (L.tiles > 2 * OS_K1CAP) return false;
+        if (L.tiles > 2 * OS_K1CAP_XL) return false;  // (a variant lists the tile counts in its candidate buffer)
         L.cand_off = coff;
         coff += (size_t)L.tiles * kTileCap * batch;
         L.count_off = noff;
@@ -787,26 +791,32 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
                        const uint32_t *tile_count, uint32_t *flat, uint32_t *lvl_ras, float *lvl_resp, int *lvl_n,
                        hipStream_t s)
 {
-    // Quotas fall with the level: levels [0, sm) need the large variant, [sm, n) fit the small one (same margins for
-    // boundary ties as orb_plan_fits: 256 at the Harris cut, 512 at the FAST-score cut)
+    // Quotas fall with the level: levels [0, xl) need the largest variant, [xl, sm) the ordinary one, [sm, n) fit the
+    // small one (margins for boundary ties: 256 at the Harris cut, 512 at the FAST-score cut)
+    auto fits = [&](int l, int lcap, int k1cap) {
+        return plan.lv[l].quota <= lcap - 256 && 2 * plan.lv[l].quota + 512 <= k1cap && plan.lv[l].tiles <= 2 * k1cap;
+    };
     int sm = plan.nlevels;
-    while (sm > 0 && plan.lv[sm - 1].quota <= OS_LCAP_S - 256 && 2 * plan.lv[sm - 1].quota + 512 <= OS_K1CAP_S &&
-           plan.lv[sm - 1].tiles <= 2 * OS_K1CAP_S)
-        sm--;
-    // (VO_OS_SMALL_FROM=n: levels below n keep the large variant, for comparisons)
+    while (sm > 0 && fits(sm - 1, OS_LCAP_S, OS_K1CAP_S)) sm--;
+    int xl = sm;
+    while (xl > 0 && fits(xl - 1, OS_LCAP, OS_K1CAP)) xl--;
+    // (VO_OS_SMALL_FROM=n: levels below n do not use the small variant, for comparisons)
     static const int force = getenv("VO_OS_SMALL_FROM") ? atoi(getenv("VO_OS_SMALL_FROM")) : -1;
     if (force >= 0) sm = std::max(sm, std::min(force, plan.nlevels));
-    if (sm > 0)
-        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, kOrbLevelCap>), dim3(batch, sm), dim3(OS_THREADS), 0, s,
+    if (xl > 0)
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP_XL, OS_LCAP_XL>), dim3(batch, xl), dim3(OS_THREADS), 0, s,
                            plan, batch, 0, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp, lvl_n);
-    if (plan.nlevels > sm) {
+    if (sm > xl)
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, OS_LCAP>), dim3(batch, sm - xl), dim3(OS_THREADS), 0, s,
+                           plan, batch, xl, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp, lvl_n);
+    if (plan.nlevels > sm)
         hipLaunchKernelGGL((k_orb_select<OS_THREADS_S, OS_K1CAP_S, OS_LCAP_S>), dim3(batch, plan.nlevels - sm),
                            dim3(OS_THREADS_S), 0, s, plan, batch, sm, 0, pyr, cand, tile_count, flat, lvl_ras, lvl_resp,
                            lvl_n);
-        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP, kOrbLevelCap>), dim3(batch, plan.nlevels - sm),
-                           dim3(OS_THREADS), 0, s, plan, batch, sm, /*redo_only=*/1, pyr, cand, tile_count, flat,
+    if (plan.nlevels > xl)  // the levels that overflowed a smaller variant
+        hipLaunchKernelGGL((k_orb_select<OS_THREADS, OS_K1CAP_XL, OS_LCAP_XL>), dim3(batch, plan.nlevels - xl),
+                           dim3(OS_THREADS), 0, s, plan, batch, xl, /*redo_only=*/1, pyr, cand, tile_count, flat,
                            lvl_ras, lvl_resp, lvl_n);
-    }
 }
 
 void launch_orb_finish(const OrbPlan &plan, int batch, const uint8_t *pyr, const uint32_t *lvl_ras,

@@ -685,7 +685,7 @@ int vo_ctx::ensure_orb(int w, int h, float scale_factor, int nlevels, int nfeatu
     if (!orb_make_plan(w, h, scale_factor, nlevels, nfeatures, batch, &p))
         return fail(ctx, VO_ERR_UNSUPPORTED,
                     "ORB pyramid %dx%d, scale %.3f, %d levels, %d features is outside the supported range "
-                    "(1 < scale <= 2, 1..8 levels, smallest level >= 7 px, <= 1792 features per level)",
+                    "(1 < scale <= 2, 1..8 levels, smallest level >= 7 px, <= 3840 features per level)",
                     w, h, (double)scale_factor, nlevels, nfeatures);
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     // a recorded batch chain holds the old plan's level tables and buffer addresses

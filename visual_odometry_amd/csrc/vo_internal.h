@@ -22,7 +22,7 @@ constexpr int kTileW = 128, kTileH = VO_TILE_H;  // tile of the fused image kern
 constexpr int kTileCap = kTileW * kTileH / 4;  // corners one tile can emit (3x3 strict maxima: one per 2x2 block)
 inline int tiles_of(int w, int h) { return ((w + kTileW - 1) / kTileW) * ((h + kTileH - 1) / kTileH); }
 constexpr int kOrbMaxLevels = 8;   // pyramid levels of the full ORB detector
-constexpr int kOrbLevelCap = 2048; // keypoints one level can contribute
+constexpr int kOrbLevelCap = 4096; // keypoints one level can contribute
 
 // floor(x / d) without a run-time division: umulhi(x, magic_inv(d)), exact while x * d < 2^32.  d = 1 has no
 // 32-bit magic number and is encoded as 0.
@@ -64,7 +64,7 @@ struct OrbPlan {
 };
 
 // false when the configuration is outside what the kernels support
-// (1 < scale_factor <= 2, 1..8 levels, smallest level >= 7 px, quota per level <= 1792)
+// (1 < scale_factor <= 2, 1..8 levels, smallest level >= 7 px, quota per level <= 3840)
 bool orb_make_plan(int w, int h, float scale_factor, int nlevels, int nfeatures, int batch, OrbPlan *out);
 
 // per-axis table of cv::resize(INTER_LINEAR_EXACT): offset | weight << 16, `padded` entries
