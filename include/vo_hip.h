@@ -461,14 +461,19 @@ typedef struct {
 int vo_batch_set_packed_output(vo_ctx *ctx, int enable);
 int vo_batch_get_packed(vo_ctx *ctx, int frame, vo_frame_view *view);
 
-/* Replay the kernel chain of a batch as one captured HIP graph instead of
- * launching its 10 to 30 kernels one by one (no counterpart in the reference;
- * it shortens the launch-bound single-frame path).  The graph is captured on
- * the first submit after enabling and again whenever the configuration, the
- * camera or the device input pointers change; host inputs go through the
- * context's staging area and never force a re-capture.  A graph replay records
- * no per-stage events: vo_batch_get_timing() returns VO_ERR_STATE after a batch
- * that ran as a graph. */
+/* Replay the kernel chain of a batch as captured HIP graphs instead of
+ * launching its 10 to 30 kernels one by one (no counterpart in the reference).
+ * The chain is captured in two parts -- everything that needs the frames only,
+ * then everything from the depth plane on, so that a depth plane in host
+ * memory can travel beside the first part -- on the first submit after
+ * enabling, and again whenever the configuration, the camera or the device
+ * input pointers change; host inputs go through the context's staging area
+ * and never force a re-capture.  It pays where the host cannot keep up with
+ * launching (many short kernels per batch on a busy CPU); for a single HD720
+ * frame on an idle core plain launches are faster, because a graph launch takes
+ * about 0.1 ms to reach the GPU.  A graph replay records no per-stage events:
+ * vo_batch_get_timing() returns VO_ERR_STATE after a batch that ran as a
+ * graph. */
 int vo_batch_set_graph(vo_ctx *ctx, int enable);
 
 /* Pinned host memory for frames and depth planes: vo_batch_submit copies from
