@@ -100,3 +100,31 @@ def test_pnp_hand_over_large_batch_equals_small_batches():
                 assert big[name][g] == small[name][b], (g, name)
             assert np.array_equal(big["rvec"][g], small["rvec"][b]) and np.array_equal(big["tvec"][g], small["tvec"][b])
             assert np.array_equal(big_inl[g], small_inl[b])
+
+
+@pytest.mark.timeout(300)
+def test_pnp_hand_over_is_the_same_launch_after_launch():
+    """Which block solves which published item depends on timing; nothing that comes out may.  The launch of the
+    test above, repeated sixty times in a large and in a small batch: result records and inlier lists identical to
+    the first launch every time."""
+    from visual_odometry_amd import capi
+    cam = synth.CONFIG_CAMERAS["vga"]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    S, F, N = 32, 4, 1000
+    frames, depth, _ = synth.make_pingpong_batch(cam, S, F, seed=53000, channels=4, relief=2.0, movers=30, workers=4)
+    for streams in (S, 8):
+        B = streams * F
+        with capi.Context(device=0, max_width=cam.width, max_height=cam.height, max_features=N + 64,
+                          max_batch=B) as c:
+            c.batch_configure(cam.width, cam.height, 4, n_streams=streams, frames_per_stream=F, max_features=N,
+                              fast_threshold=20, camera=K, orb_levels=8)
+            ref = None
+            for k in range(60):
+                c.batch_reset()
+                c.batch_submit(frames[:B], depth[:B])
+                res = c.batch_wait()
+                cur = (res.tobytes(), [c.batch_inliers(b).tobytes() for b in range(0, B, 3)])
+                if ref is None:
+                    ref = cur
+                    assert (res["pnp_iters"] > 18).sum() >= 1, "the batch must contain a frame that is handed over"
+                assert cur == ref, (streams, k)
