@@ -3,7 +3,9 @@ times on the GPU and compare every launch with the first repeatable one bit for 
 and poses.  The hand-over is lock-free (atomics, no block waits for another); which block solves which item
 differs from launch to launch, the outputs must not.
 
-    python3 tools/soak_hard.py [launches] [streams] [frames_per_stream]      (GPU box)
+    python3 tools/soak_hard.py [launches] [streams] [frames_per_stream] [movers] [relief]      (GPU box)
+
+movers = 0 gives the benchmark's ordinary scene, relief = 0 the flat wall (the planar branch of the refinement).
 """
 import os
 import sys
@@ -20,7 +22,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     F = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-    cam, f, d, _ = bench.build_inputs(S, F, seed=52000, movers=bench.HARD_SCENE_MOVERS, workers=16)
+    movers = int(sys.argv[4]) if len(sys.argv) > 4 else bench.HARD_SCENE_MOVERS
+    relief = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0
+    cam, f, d, _ = bench.build_inputs(S, F, seed=52000, movers=movers, workers=16, relief=relief,
+                                      tilt=(0.0, 0.0) if relief else (0.08, -0.05))
     dev = torch.device("cuda:0")
     fd, dd = torch.from_numpy(f).to(dev), torch.from_numpy(d).to(dev)
     B = S * F
@@ -44,7 +49,7 @@ def main():
             if cur[0] != ref[0] or cur[1] != ref[1]:
                 bad += 1
                 print("launch", k, "differs", flush=True)
-        print(f"{n} launches of {B} frames, {bad} differ from the reference launch; pose success "
+        print(f"movers {movers} relief {relief}: {n} launches of {B} frames, {bad} differ from the reference launch; pose success "
               f"{float(ref[2]['pnp_success'].mean()):.3f}" + (f", PnP iterations max {int(iters.max())}" if iters is not None else ""))
         return 1 if bad else 0
 
