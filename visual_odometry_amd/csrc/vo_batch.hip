@@ -695,7 +695,9 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             // the temporal matcher runs)
             (void)hipMemsetAsync(c->d_st_n, 0, sizeof(int) * B, c->stream);
             launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, S, r_slot0, B, st->band,
-                                st->min_disparity, st->max_disparity, st->ratio, b.fx, st->baseline, kKnnSplits,
+                                st->min_disparity, st->max_disparity, st->ratio, b.fx, st->baseline,
+                                reinterpret_cast<uint16_t *>(c->d_st_index),
+                                reinterpret_cast<int *>(c->d_st_index + c->st_rows_off),
                                 c->d_partial, c->d_partial_rev, c->d_st_idx, c->d_st_disp, c->d_st_depth,
                                 reinterpret_cast<uint32_t *>(c->d_depth), b.width, b.height, c->d_st_n, c->stream);
         }

@@ -209,7 +209,7 @@ void vo_ctx::release()
     stager_stop();
     void *ptrs[] = {d_in, d_gray, d_score, d_blur, d_cand, d_cand_flat, d_cand_count, d_orb_cand_flat, d_kps, d_desc, d_nkp, d_pattern,
                     d_partial, d_partial_rev, d_knn, d_good, d_ngood, d_mask, d_F, d_info, d_final, d_qslot, d_tslot, d_rng, d_aux, d_hist, d_pattern0, d_orb_tab, d_eq, d_eE, d_eidx, d_enm, d_ecnt, d_einfo, d_emask,
-                    d_st_idx, d_st_disp, d_st_depth, d_st_plane, d_st_n,
+                    d_st_idx, d_st_disp, d_st_depth, d_st_plane, d_st_n, d_st_index,
                     d_pyr, d_pyr_blur, d_orb_cand, d_orb_cand_count, d_lvl_ras, d_lvl_resp, d_lvl_n,
                     d_depth, d_ages, d_has_prev, d_filter_flag, d_tracked, d_valid, d_pts3, d_bpinfo,
                     d_inliers, d_pose, d_rt, d_results, d_pnp2};
@@ -585,6 +585,7 @@ int vo_ctx::ensure_stereo()
     HIP_TRY(ctx, hipMalloc(&d_st_disp, sizeof(float) * n));
     HIP_TRY(ctx, hipMalloc(&d_st_depth, sizeof(float) * n));
     HIP_TRY(ctx, hipMalloc(&d_st_n, sizeof(int) * cfg.max_batch));
+    HIP_TRY(ctx, hipMalloc(&d_st_index, stereo_index_bytes(cfg.max_batch, kp_stride, &st_rows_off)));
     return VO_OK;
 }
 
@@ -637,8 +638,9 @@ int vo_stereo_depth(vo_ctx *c, const vo_kp *left_kps, const uint8_t *left_desc, 
         if ((rc = upload_features(c, c->op_slot1, right_kps, right_desc, n_right))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_st_n, 0, sizeof(int), c->stream));
         launch_stereo_match(c->d_kps, c->d_desc, c->d_nkp, c->kp_stride, c->op_slot0, c->op_slot1, 1, band, min_disp,
-                            max_disp, ratio, fx, baseline, kKnnSplits, c->d_partial, c->d_partial_rev, c->d_st_idx,
-                            c->d_st_disp, c->d_st_depth, d_plane, w, h, c->d_st_n, c->stream);
+                            max_disp, ratio, fx, baseline, reinterpret_cast<uint16_t *>(c->d_st_index),
+                            reinterpret_cast<int *>(c->d_st_index + c->st_rows_off), c->d_partial, c->d_partial_rev,
+                            c->d_st_idx, c->d_st_disp, c->d_st_depth, d_plane, w, h, c->d_st_n, c->stream);
         if ((rc = finish(c, "vo_stereo_depth"))) return rc;
         HIP_TRY(c, hipMemcpy(right_idx, c->d_st_idx, sizeof(int32_t) * n_left, hipMemcpyDefault));
         HIP_TRY(c, hipMemcpy(disparity, c->d_st_disp, sizeof(float) * n_left, hipMemcpyDefault));

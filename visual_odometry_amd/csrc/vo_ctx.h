@@ -73,6 +73,8 @@ struct vo_ctx {
     int32_t *d_st_idx = nullptr;
     float *d_st_disp = nullptr, *d_st_depth = nullptr, *d_st_plane = nullptr;
     int *d_st_n = nullptr;
+    uint8_t *d_st_index = nullptr;  // row lists of both key-point sets of every frame (launch_stereo_match)
+    size_t st_rows_off = 0;
     size_t st_plane_cap = 0;
     int ensure_stereo();
     bool depth_planes_nan = false;  // d_depth holds nothing but NaN (stereo batches keep it that way)

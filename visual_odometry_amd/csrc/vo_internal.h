@@ -148,17 +148,20 @@ void launch_enhance_blur_mask(const uint8_t *src, int w, int h, int pitch, const
                               const uint16_t *taps, uint8_t *enh, uint8_t *den, uint8_t *msk, hipStream_t s);
 
 // Stereo front end, batched over `frames` pairs: left key points in feature slots
-// l_slot0 + f, right ones in r_slot0 + f.  Band-limited Hamming matching
-// left->right and right->left (two smallest keys per query and train split in
-// fwd / bwd, frames x kp_stride x splits), then ratio test, cross-check,
+// l_slot0 + f, right ones in r_slot0 + f.  Both sets are listed by image row
+// (order / row_start: scratch of stereo_index_bytes(frames, kp_stride) bytes, the
+// row table *rows_off bytes into it), then band-limited Hamming matching
+// left->right and right->left over the rows of each query's band (two smallest
+// keys per query in fwd / bwd, frames x kp_stride), then ratio test, cross-check,
 // disparity, depth = fx * baseline / disparity (per-key-point arrays of
 // frames x kp_stride, may be null) and an atomic-minimum scatter into the
 // frames x h x w depth planes (all 0xff bytes = NaN beforehand; may be null).
 // n_matched (frames entries, may be null) must be zero on entry.
 void launch_stereo_match(const vo_kp *kps, const uint8_t *desc, const int *nkp, int kp_stride, int l_slot0,
                          int r_slot0, int frames, float band, float min_disp, float max_disp, float ratio, double fx,
-                         double baseline, int splits, uint2 *fwd, uint2 *bwd, int32_t *right_idx, float *disparity,
-                         float *depth, uint32_t *plane, int w, int h, int *n_matched, hipStream_t s);
+                         double baseline, uint16_t *order, int *row_start, uint2 *fwd, uint2 *bwd, int32_t *right_idx,
+                         float *disparity, float *depth, uint32_t *plane, int w, int h, int *n_matched, hipStream_t s);
+size_t stereo_index_bytes(int frames, int kp_stride, size_t *rows_off);
 // Puts NaN back at every pixel a left key point of the batch rounds to.
 void launch_stereo_clear(const vo_kp *kps, const int *nkp, int kp_stride, int l_slot0, int frames, uint32_t *plane,
                          int w, int h, hipStream_t s);
