@@ -93,16 +93,20 @@ def test_orb_tie_class_beyond_the_small_ranking_lists(big_ctx, oracle):
     assert 1536 < inside.sum() <= 4096 and len(np.unique(c["response"][inside])) == 1   # the premise
     k, d = big_ctx.detect_orb(img, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20, cap=N)
     assert len(kr) > 1000 and np.array_equal(k, kr) and np.array_equal(d, dr)
+    # batches of 32 frames and more rank their levels in the small blocks: the pattern beside an ordinary frame
+    from visual_odometry_amd import capi
     rng = np.random.default_rng(9)
     other = rng.integers(0, 256, (h, w), dtype=np.uint8)
     ko, do = oracle.orb_detect(other, nfeatures=2000, scale_factor=1.2, nlevels=8, fast_threshold=20)
-    big_ctx.batch_configure(w, h, 1, n_streams=1, frames_per_stream=2, max_features=2000, fast_threshold=20,
-                            orb_levels=8)
-    big_ctx.batch_submit(np.stack([other, img]), None)
-    big_ctx.batch_wait()
-    for f, (a, b) in enumerate(((ko, do), (kr, dr))):
-        kk, dd = big_ctx.batch_features(f)
-        assert np.array_equal(kk, a[:2000]) and np.array_equal(dd, b[:2000]), f
+    with capi.Context(device=0, max_width=w, max_height=h, max_features=2000, max_batch=32) as c:
+        c.batch_configure(w, h, 1, n_streams=16, frames_per_stream=2, max_features=2000, fast_threshold=20,
+                          orb_levels=8)
+        c.batch_submit(np.stack([other, img] * 16), None)
+        c.batch_wait()
+        for f in (0, 1, 30, 31):
+            a, b = ((ko, do), (kr, dr))[f & 1]
+            kk, dd = c.batch_features(f)
+            assert np.array_equal(kk, a[:2000]) and np.array_equal(dd, b[:2000]), f
 
 
 def test_largest_frame(oracle):

@@ -797,7 +797,10 @@ void launch_orb_select(const OrbPlan &plan, int batch, const uint8_t *pyr, const
         return plan.lv[l].quota <= lcap - 256 && 2 * plan.lv[l].quota + 512 <= k1cap && plan.lv[l].tiles <= 2 * k1cap;
     };
     int sm = plan.nlevels;
-    while (sm > 0 && fits(sm - 1, OS_LCAP_S, OS_K1CAP_S)) sm--;
+    // (a handful of frames cannot fill the chip with blocks anyway: there the larger block finishes a level sooner,
+    // 0.54 against 0.56 ms for one HD720 frame through the facade)
+    if (batch >= 32)
+        while (sm > 0 && fits(sm - 1, OS_LCAP_S, OS_K1CAP_S)) sm--;
     int xl = sm;
     while (xl > 0 && fits(xl - 1, OS_LCAP, OS_K1CAP)) xl--;
     // (VO_OS_SMALL_FROM=n: levels below n do not use the small variant, for comparisons)
