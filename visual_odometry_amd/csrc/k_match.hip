@@ -115,8 +115,8 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
     }
 
     // this block's share of the train set: an even cut of the descriptors
-    const int j_lo = (int)(((long long)nt * split) / kKnnSplits);
-    const int j_hi = (int)(((long long)nt * (split + 1)) / kKnnSplits);
+    const int j_lo = (int)(((long long)nt * split) / (int)gridDim.y);
+    const int j_hi = (int)(((long long)nt * (split + 1)) / (int)gridDim.y);
     const int ntiles = (j_hi - j_lo + KNN_TILE - 1) / KNN_TILE;
 
     // staging role of this thread: word sc of train sr of the tile
@@ -255,7 +255,7 @@ void k_knn2(const uint8_t *__restrict__ desc, size_t slot_stride, const int *__r
         };
         const int q = qbase + wave * KNN_QPW + 32 * s + col;
         if (half == 0 && q < nq)
-            partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(finish(n0), finish(n1));
+            partial[((size_t)pair * gridDim.y + split) * kp_stride + q] = make_uint2(finish(n0), finish(n1));
     }
 }
 
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(KNP_THREADS) void k_knn2_popcount(const uint8_t *__
     }
 
     // this block's share of the train set: an even cut of the descriptors
-    const int j_lo = (int)(((long long)nt * split) / kKnnSplits);
-    const int j_hi = (int)(((long long)nt * (split + 1)) / kKnnSplits);
+    const int j_lo = (int)(((long long)nt * split) / (int)gridDim.y);
+    const int j_hi = (int)(((long long)nt * (split + 1)) / (int)gridDim.y);
 
     for (int j0 = j_lo; j0 < j_hi; j0 += KNP_TILE) {
         const int jn = min(KNP_TILE, j_hi - j0);
@@ -347,21 +347,30 @@ __global__ __launch_bounds__(KNP_THREADS) void k_knn2_popcount(const uint8_t *__
 #pragma unroll
     for (int i = 0; i < KNP_QPL; i++) {
         const int q = qbase + i * KNP_THREADS + (int)threadIdx.x;
-        if (q < nq) partial[((size_t)pair * kKnnSplits + split) * kp_stride + q] = make_uint2(k0[i], k1[i]);
+        if (q < nq) partial[((size_t)pair * gridDim.y + split) * kp_stride + q] = make_uint2(k0[i], k1[i]);
     }
 }
 
+// The train set is cut in two across blocks when the launch has pairs enough to fill the chip, in eight when it
+// has not (a single pair of 1000 x 1000 is 8 blocks against 32: 12.6 -> about 6 us).
+int knn_splits(int pairs, int max_n)
+{
+    const int query_blocks = (max_n + KNN_QPB - 1) / KNN_QPB;
+    // (fewer than 64 pairs whenever the larger number is chosen: the partial buffers are sized for that)
+    return pairs >= 64 || (long long)pairs * query_blocks * kKnnSplits >= 128 ? kKnnSplits : kKnnSplitsFew;
+}
+
 void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp, const int *q_slot,
-                 const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, bool popcount,
+                 const int *t_slot, int kp_stride, uint2 *partial, int max_n, int pairs, int splits, bool popcount,
                  hipStream_t s, unsigned long long *stamp)
 {
     if (popcount) {
-        dim3 grid((max_n + KNP_QPB - 1) / KNP_QPB, kKnnSplits, pairs);
+        dim3 grid((max_n + KNP_QPB - 1) / KNP_QPB, splits, pairs);
         hipLaunchKernelGGL(k_knn2_popcount, grid, dim3(KNP_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot,
                            t_slot, kp_stride, partial, stamp);
         return;
     }
-    dim3 grid((max_n + KNN_QPB - 1) / KNN_QPB, kKnnSplits, pairs);
+    dim3 grid((max_n + KNN_QPB - 1) / KNN_QPB, splits, pairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(KNN_THREADS), 0, s, desc, slot_stride_bytes, nkp, q_slot, t_slot,
                        kp_stride, partial, stamp);
 }
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
                                                                 const uint2 *__restrict__ partial_rev,
                                                                 vo_knn2 *__restrict__ knn,
                                                                 vo_match *__restrict__ good,
-                                                                int *__restrict__ n_good)
+                                                                int *__restrict__ n_good, int splits)
 {
     __shared__ int s_wave[FIN_THREADS / kWave];
     __shared__ int s_base;
@@ -404,10 +413,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
         vo_knn2 r = {-1, 0, -1, 0};
         if (q < nq && nt > 0) {
             uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
-#pragma unroll
-            for (int s = 0; s < kKnnSplits; s++) {
+            for (int s = 0; s < splits; s++) {
                 // every split writes its slot (0xffffffff keys when its share is empty)
-                const uint2 p = partial[((size_t)pair * kKnnSplits + s) * kp_stride + q];
+                const uint2 p = partial[((size_t)pair * splits + s) * kp_stride + q];
                 uint32_t key = p.x;
                 uint32_t n0 = min(k0, key);
                 k1 = min(k1, max(k0, key));
@@ -424,9 +432,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
             if (keep && partial_rev) {
                 // cross-check: q must also be the nearest query of its best train descriptor
                 uint32_t b0 = 0xffffffffu;
-#pragma unroll
-                for (int s = 0; s < kKnnSplits; s++)
-                    b0 = min(b0, partial_rev[((size_t)pair * kKnnSplits + s) * kp_stride + r.idx0].x);
+                for (int s = 0; s < splits; s++)
+                    b0 = min(b0, partial_rev[((size_t)pair * splits + s) * kp_stride + r.idx0].x);
                 keep = (int)(b0 & 0xffffu) == q;
             }
         } else if (q < nq && knn) {
@@ -459,10 +466,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_match_finalize(const uint2 *__r
 
 void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride, const int *nkp,
                            const int *q_slot, const int *t_slot, float ratio, const uint2 *partial_rev,
-                           vo_knn2 *knn, vo_match *good, int *n_good, int pairs, hipStream_t s)
+                           vo_knn2 *knn, vo_match *good, int *n_good, int pairs, int splits, hipStream_t s)
 {
     hipLaunchKernelGGL(k_match_finalize, dim3(pairs), dim3(FIN_THREADS), 0, s, partial, kps, kp_stride, nkp,
-                       q_slot, t_slot, ratio, partial_rev, knn, good, n_good);
+                       q_slot, t_slot, ratio, partial_rev, knn, good, n_good, splits);
 }
 
 }  // namespace vo

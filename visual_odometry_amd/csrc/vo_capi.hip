@@ -140,8 +140,10 @@ int vo_ctx::allocate()
     HIP_TRY(ctx, hipMalloc(&d_desc, (size_t)32 * kp_stride * slots));
     HIP_TRY(ctx, hipMalloc(&d_nkp, sizeof(int) * slots));
     HIP_TRY(ctx, hipMalloc(&d_pattern, 1024));
-    HIP_TRY(ctx, hipMalloc(&d_partial, sizeof(uint2) * (size_t)kKnnSplits * kp_stride * B));
-    HIP_TRY(ctx, hipMalloc(&d_partial_rev, sizeof(uint2) * (size_t)kKnnSplits * kp_stride * B));
+    // (knn_splits() picks kKnnSplitsFew only for launches of fewer than 64 pairs)
+    const size_t partial_slots = std::max((size_t)kKnnSplits * B, (size_t)kKnnSplitsFew * std::min(B, 64));
+    HIP_TRY(ctx, hipMalloc(&d_partial, sizeof(uint2) * partial_slots * kp_stride));
+    HIP_TRY(ctx, hipMalloc(&d_partial_rev, sizeof(uint2) * partial_slots * kp_stride));
     HIP_TRY(ctx, hipMalloc(&d_knn, sizeof(vo_knn2) * (size_t)kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_good, sizeof(vo_match) * (size_t)kp_stride * B));
     HIP_TRY(ctx, hipMalloc(&d_ngood, sizeof(int) * B));
@@ -497,10 +499,11 @@ int vo_knn2_hamming(vo_ctx *c, const uint8_t *query, int nq, const uint8_t *trai
     if ((rc = upload_features(c, c->op_slot0, nullptr, query, nq))) return rc;
     if ((rc = upload_features(c, c->op_slot1, nullptr, train, nt))) return rc;
     if ((rc = set_single_pair(c))) return rc;
+    const int splits = knn_splits(1, std::max(nq, 1));
     launch_knn2(c->d_desc, (size_t)c->kp_stride * 32, c->d_nkp, c->d_qslot, c->d_tslot, c->kp_stride,
-                c->d_partial, c->kp_stride, 1, c->matcher_popcount, c->stream);
+                c->d_partial, std::max(nq, 1), 1, splits, c->matcher_popcount, c->stream);
     launch_match_finalize(c->d_partial, c->d_kps, c->kp_stride, c->d_nkp, c->d_qslot, c->d_tslot, 0.7f, nullptr,
-                          c->d_knn, c->d_good, c->d_ngood, 1, c->stream);
+                          c->d_knn, c->d_good, c->d_ngood, 1, splits, c->stream);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_knn, sizeof(vo_knn2) * nq, hipMemcpyDefault, c->stream));
     return finish(c, "vo_knn2_hamming");
 }
@@ -792,15 +795,16 @@ void vo_ctx::enqueue_detect_orb(const uint8_t *src, int w, int h, int src_stride
 void vo_ctx::enqueue_match(int pairs, float ratio, bool cross_check, FRansacParams prm)
 {
     mark(5);
+    const int splits = knn_splits(pairs, kp_stride);
     launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_qslot, d_tslot, kp_stride, d_partial, kp_stride,
-                pairs, matcher_popcount, stream, pending_stamp);
+                pairs, splits, matcher_popcount, stream, pending_stamp);
     pending_stamp = nullptr;
     if (cross_check)  // the same pairs with the roles of query and train swapped
         launch_knn2(d_desc, (size_t)kp_stride * 32, d_nkp, d_tslot, d_qslot, kp_stride, d_partial_rev, kp_stride,
-                    pairs, matcher_popcount, stream);
+                    pairs, splits, matcher_popcount, stream);
     mark(6);
     launch_match_finalize(d_partial, d_kps, kp_stride, d_nkp, d_qslot, d_tslot, ratio,
-                          cross_check ? d_partial_rev : nullptr, d_knn, d_good, d_ngood, pairs, stream);
+                          cross_check ? d_partial_rev : nullptr, d_knn, d_good, d_ngood, pairs, splits, stream);
     mark(7);
     launch_f_ransac(d_good, d_ngood, kp_stride, d_rng, rng_len, prm, d_mask, d_F, d_info, d_final, pairs,
                     stream);

@@ -13,6 +13,7 @@ constexpr int kSelectCap = 8192;   // keys the selection kernel can sort in LDS
 constexpr int kMaxDim = 4096;      // largest width/height (row histogram bins)
 constexpr int kResizeRowPad = 32;  // rows of a resize tile: the row tables of the pyramid are padded to it
 constexpr int kKnnSplits = 2;      // train-set splits per query block
+constexpr int kKnnSplitsFew = 8;   // ... when the launch has few pairs (the partial buffers hold max(2 x batch, 8) splits)
 constexpr int kFBorder = 31;       // ORB edgeThreshold
 constexpr int kBriefReach = 18;    // the rotated rBRIEF pattern samples at most this far from a key point
 #ifndef VO_TILE_H
@@ -131,11 +132,14 @@ void launch_brief(PlaneBatch blur, const vo_kp *kps, int kp_stride,
                   int batch, hipStream_t s);
 
 // Hamming kNN-2. For pair p the query set is (q_desc + q_slot[p]*slot_stride,
-// n[q_slot[p]]) and the train set likewise. partial: [pair][split][kp_stride] uint2.
+// n[q_slot[p]]) and the train set likewise. partial: [pair][split][kp_stride] uint2, `splits` of them per pair
+// (knn_splits(pairs, max_n): kKnnSplits, or kKnnSplitsFew for launches of a few pairs; the same number goes to
+// launch_match_finalize).
 // popcount: the XOR / popcount kernel on the vector ALU instead of the matrix-core kernel (same results).
+int knn_splits(int pairs, int max_n);
 void launch_knn2(const uint8_t *desc, size_t slot_stride_bytes, const int *nkp,
                  const int *q_slot, const int *t_slot, int kp_stride,
-                 uint2 *partial, int max_n, int pairs, bool popcount, hipStream_t s,
+                 uint2 *partial, int max_n, int pairs, int splits, bool popcount, hipStream_t s,
                  unsigned long long *stamp = nullptr);
 
 // ImageProcessor stages (reference src/image_processor.cpp:41-79), one plane.
@@ -177,7 +181,7 @@ void launch_undistort(const uint8_t *src, int w, int h, int spitch, double fx, d
 void launch_match_finalize(const uint2 *partial, const vo_kp *kps, int kp_stride,
                            const int *nkp, const int *q_slot, const int *t_slot,
                            float ratio, const uint2 *partial_rev, vo_knn2 *knn,
-                           vo_match *good, int *n_good, int pairs, hipStream_t s);
+                           vo_match *good, int *n_good, int pairs, int splits, hipStream_t s);
 
 struct FRansacParams {
     double threshold, confidence;

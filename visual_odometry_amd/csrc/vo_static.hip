@@ -114,9 +114,10 @@ int vo_knn2_hamming_static(int device, void *hip_stream, const uint8_t *query, i
         return fail(VO_ERR_HIP, "copy of the query descriptors", e);
     if (nt > 0 && (e = hipMemcpyAsync(desc + slot_bytes, train, (size_t)nt * 32, hipMemcpyDefault, s)) != hipSuccess)
         return fail(VO_ERR_HIP, "copy of the train descriptors", e);
-    launch_knn2(desc, slot_bytes, ctl, ctl + 2, ctl + 3, kStaticMax, partial, nq, 1, false, s);
+    launch_knn2(desc, slot_bytes, ctl, ctl + 2, ctl + 3, kStaticMax, partial, nq, 1, kKnnSplits, false, s);
     // ratio 0 keeps nothing, so the merge kernel touches neither key points nor a match list
-    launch_match_finalize(partial, nullptr, kStaticMax, ctl, ctl + 2, ctl + 3, 0.0f, nullptr, knn, nullptr, ctl + 4, 1, s);
+    launch_match_finalize(partial, nullptr, kStaticMax, ctl, ctl + 2, ctl + 3, 0.0f, nullptr, knn, nullptr, ctl + 4, 1,
+                          kKnnSplits, s);
     if ((e = hipGetLastError()) != hipSuccess) return fail(VO_ERR_HIP, "kernel launch", e);
     if ((e = hipMemcpyAsync(out, knn, sizeof(vo_knn2) * (size_t)nq, hipMemcpyDefault, s)) != hipSuccess)
         return fail(VO_ERR_HIP, "copy of the result", e);
