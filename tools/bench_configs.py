@@ -67,7 +67,10 @@ def run_pipeline(name, cam_name, channels, streams, frames, features, stereo, cr
            "mean_matches": float(res["n_matches"].mean()), "mean_3d_points": float(res["n_3d"].mean()),
            "pose_success_rate": float(res["pnp_success"].mean()),
            "median_translation_error_mm": float(np.median(t_err)) if t_err else None,
-           "ground_truth_step_mm": float(np.linalg.norm(truth[1][1]))}
+           "ground_truth_step_mm": float(np.linalg.norm(truth[1][1])),
+           "pnp_iterations": {"mean": float(res["pnp_iters"].mean()), "max": int(res["pnp_iters"].max()),
+                              "above_8": int((res["pnp_iters"] > 8).sum())},
+           "f_ransac_iterations_mean": float(res["f_iters"].mean()) if "f_iters" in res.dtype.names else None}
     ctx.close()
     print(json.dumps(out), flush=True)
 
