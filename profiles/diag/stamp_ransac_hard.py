@@ -26,7 +26,7 @@ def main():
     movers = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     F = 16
-    cam = synth.CONFIG_CAMERAS["hd720"]
+    cam = synth.CONFIG_CAMERAS[os.environ.get("VO_DIAG_CAM", "hd720")]   # (VO_DIAG_CAM=kitti: the KITTI-shaped frames)
     flat = len(sys.argv) > 3 and sys.argv[3] == "flat"   # the flat-wall scene of the benchmark instead
     if flat:
         f, d, _ = synth.make_pingpong_batch(cam, S, F, 72000, channels=4, relief=0.0, movers=0, workers=16,
@@ -79,6 +79,10 @@ def main():
             print(f"PnP   {nme:34s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
         tot = t[:, 10] - t[:, 0]
         print("PnP whole block: median %d p90 %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max()))
+        if os.environ.get("VO_DIAG_DUMP"):   # the null-vector phase (identical work in every block) block by block
+            nb = min(256, S * F)
+            print("PnP null vector by block:", (t[:nb, 8] - t[:nb, 7]).tolist())
+            print("PnP start by block:", (t[:nb, 0] - t[:nb, 0].min()).tolist())
         if hasattr(raw, "vo_debug_pnp_blocks"):
             pb = np.zeros((1024, 8), np.uint64)
             raw.vo_debug_pnp_blocks.argtypes = [C.c_void_p]
