@@ -150,24 +150,33 @@ static void svd12_onesided(const double *Gcm, int rows, double *w, double *Vt)
                 if (x > y) continue;
                 double *gp = G[x], *gq = G[y];
                 double alpha = 0, beta = 0, gamma = 0;
-                for (int i = 0; i < rows; i++) alpha += gp[i] * gp[i];
-                for (int i = 0; i < rows; i++) beta += gq[i] * gq[i];
-                for (int i = 0; i < rows; i++) gamma += gp[i] * gq[i];
-                if (fabs(gamma) <= eps * sqrt(alpha * beta) || fabs(gamma) <= 1e-26 * frob) continue;
+                /* the three sums and the rotation below are chains of fused multiply-adds (one rounding per term) */
+                for (int i = 0; i < rows; i++) alpha = fma(gp[i], gp[i], alpha);
+                for (int i = 0; i < rows; i++) beta = fma(gq[i], gq[i], beta);
+                for (int i = 0; i < rows; i++) gamma = fma(gp[i], gq[i], gamma);
+                /* |gamma| <= eps sqrt(alpha beta), squared */
+                if (gamma * gamma <= (eps * eps) * (alpha * beta) || fabs(gamma) <= 1e-26 * frob) continue;
                 rotated = 1;
-                double zeta = (beta - alpha) / (2 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                double c = 1 / sqrt(1 + t * t), sn = c * t;
+                /* tan and cos of the angle: d = beta - alpha, h = 2 gamma, r = sqrt(d^2 + h^2),
+                 * tan = sign(d) h / (|d| + r), cos^2 = (|d| + r) / (2 r), both as multiples of the one reciprocal
+                 * 1 / (2 r (|d| + r)); at d = 0 either sign of tan annihilates gamma and + h is taken */
+                double d = beta - alpha, h = 2 * gamma;
+                double rr = sqrt(d * d + h * h);
+                double den = fabs(d) + rr, r2 = 2 * rr;
+                double w = 1.0 / (r2 * den);
+                double sh = d < 0 ? -h : h;
+                double t = (sh * r2) * w;
+                double c = sqrt((den * den) * w), sn = c * t;
                 for (int i = 0; i < rows; i++) {
                     double a = gp[i], b = gq[i];
-                    gp[i] = c * a - sn * b;
-                    gq[i] = sn * a + c * b;
+                    gp[i] = fma(-sn, b, c * a);
+                    gq[i] = fma(sn, a, c * b);
                 }
                 double *vp = V[x], *vq = V[y];
                 for (int i = 0; i < 12; i++) {
                     double a = vp[i], b = vq[i];
-                    vp[i] = c * a - sn * b;
-                    vq[i] = sn * a + c * b;
+                    vp[i] = fma(-sn, b, c * a);
+                    vq[i] = fma(sn, a, c * b);
                 }
             }
         if (!rotated) break;

@@ -380,6 +380,23 @@ __device__ __forceinline__ int rr_partner(int x, int r)
     return y < 0 ? y + 11 : y;
 }
 
+// sqrt(x) for x well inside the normal range (here: sums of squares of matrix entries that the rotation test has
+// found to be far from zero).  The reciprocal-square-root estimate refined by the two coupled Newton steps and the
+// residual corrections that yield the correctly rounded root -- the compiler's own expansion of sqrt() without the
+// rescaling of tiny arguments and the pass-through of 0 and infinity, which cannot occur here.
+__device__ __forceinline__ double sqrt_normal(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    return fma(e, h, g);
+}
+
 // Right singular vectors of a ROWS x 12 matrix whose column gl lives in
 // g[] of lane gl of each PR_GROUP-lane group (lanes past the last whole group idle).  On return v[] is the group's column
 // gl of V and *norm2 the squared norm of the rotated column gl (a squared
@@ -409,15 +426,18 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
 #pragma unroll
             for (int i = 0; i < ROWS; i++) pg[i] = __shfl(g[i], src);
             const bool am_p = gl < y;
-            double so = 0, gamma = 0;
+            // both squared norms are summed here, the partner's from the copy just fetched: it is the sum the partner
+            // lane forms of its own column, term by term, and costs no further exchange
+            double so = 0, sp = 0, gamma = 0;
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) so += g[i] * g[i];
-            // (the partner lane has just summed its own column the same way)
-            const double sp = __shfl(so, src);
+            for (int i = 0; i < ROWS; i++) so = fma(g[i], g[i], so);
 #pragma unroll
-            for (int i = 0; i < ROWS; i++) gamma += g[i] * pg[i];
+            for (int i = 0; i < ROWS; i++) sp = fma(pg[i], pg[i], sp);
+#pragma unroll
+            for (int i = 0; i < ROWS; i++) gamma = fma(g[i], pg[i], gamma);
             const double alpha = am_p ? so : sp, beta = am_p ? sp : so;
-            const bool skip = !col || fabs(gamma) <= eps * sqrt(alpha * beta) || fabs(gamma) <= 1e-26 * frob;
+            // |gamma| <= eps sqrt(alpha beta), squared: the test then waits for no square root
+            const bool skip = !col || gamma * gamma <= (eps * eps) * (alpha * beta) || fabs(gamma) <= 1e-26 * frob;
             if (!skip) {
                 // (both lanes of a pair see the same alpha, beta and gamma -- a product does not depend on the order
                 // of its factors -- so they are here together and can exchange their columns of V)
@@ -425,16 +445,24 @@ __device__ void group_svd12(double (&g)[ROWS], double (&v)[12], int gl, double *
 #pragma unroll
                 for (int i = 0; i < 12; i++) pv[i] = __shfl(v[i], src);
                 rotated = true;
-                const double zeta = (beta - alpha) / (2 * gamma);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-                const double c = 1 / sqrt(1 + t * t), sn = c * t;
-                // the lower column of the pair becomes c p - s q, the upper one s p + c q: one expression for both
-                // (a - b and a + (-b) round alike, and so do a + b and b + a)
+                // tan and cos of the rotation angle: with d = beta - alpha, h = 2 gamma and r = sqrt(d^2 + h^2),
+                // tan = sign(d) h / (|d| + r) and cos^2 = (|d| + r) / (2 r), both as multiples of the one reciprocal
+                // 1 / (2 r (|d| + r)).  (At d = 0 either sign of tan annihilates gamma; + h is taken.)
+                const double d = beta - alpha, h = 2 * gamma;
+                const double rr = sqrt_normal(d * d + h * h);
+                const double den = fabs(d) + rr, r2 = 2 * rr;
+                const double w = 1.0 / (r2 * den);
+                const double sh = d < 0 ? -h : h;
+                const double t = (sh * r2) * w;
+                const double c = sqrt_normal((den * den) * w), sn = c * t;
+                // the lower column of the pair becomes c p - s q, the upper one c q + s p, each as the partner's
+                // term fused onto the rounded product of the own one: one expression for both
+                // ((-s) q and -(s q) are the same number)
                 const double s2 = am_p ? -sn : sn;
 #pragma unroll
-                for (int i = 0; i < ROWS; i++) g[i] = c * g[i] + s2 * pg[i];
+                for (int i = 0; i < ROWS; i++) g[i] = fma(s2, pg[i], c * g[i]);
 #pragma unroll
-                for (int i = 0; i < 12; i++) v[i] = c * v[i] + s2 * pv[i];
+                for (int i = 0; i < 12; i++) v[i] = fma(s2, pv[i], c * v[i]);
             }
         }
         if (!__any(rotated)) break;
