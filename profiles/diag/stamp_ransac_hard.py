@@ -77,6 +77,8 @@ def main():
         for i, nme in enumerate(["solver: control points", "solver: singular vectors", "solver: betas + pose"]):
             dlt = t[:, 12 + i] - t[:, 11 + i]
             print(f"PnP   {nme:34s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
+        for nme, dlt in (("solver: subset + load", t[:, 11] - t[:, 2]), ("solver: pick + Rodrigues + barrier", t[:, 3] - t[:, 14])):
+            print(f"PnP   {nme:34s} median {np.median(dlt):9.0f} p90 {np.percentile(dlt, 90):9.0f}")
         tot = t[:, 10] - t[:, 0]
         print("PnP whole block: median %d p90 %d max %d" % (np.median(tot), np.percentile(tot, 90), tot.max()))
         if os.environ.get("VO_DIAG_DUMP"):   # the null-vector phase (identical work in every block) block by block

@@ -1384,9 +1384,10 @@ extern "C" int vo_debug_pnp_blocks(unsigned long long *out)
 #endif
 
 // solve hypotheses first_h .. first_h + per_wave - 1 of the round (those below nc), one per group of PR_GROUP
-// lanes; all lanes of the wave call
-__device__ void solve_hypothesis(PrShared &S, const float *obj, const float *img, int first_h, int per_wave, int nc,
-                                 double fx, double fy, double cx, double cy)
+// lanes; all lanes of the wave call.  A function of its own on purpose: it needs nearly every register, and inlined
+// into the kernel its loops pick up spills.  (The kernel carries disable_tail_calls for its sake: see there.)
+static __device__ __noinline__ void solve_hypothesis(PrShared &S, const float *obj, const float *img, int first_h,
+                                                     int per_wave, int nc, double fx, double fy, double cx, double cy)
 {
     const int lane = threadIdx.x & 63, grp = lane / PR_GROUP, gl = lane - grp * PR_GROUP;
     const bool member = grp < per_wave;  // the other lanes of the wave follow along idle
@@ -2119,7 +2120,11 @@ __device__ __forceinline__ void pnp_replay(PrShared &S, const PnpArgs &a, int b,
 
 // out: pose[b] = {success, n_inliers, iters_run, n_points}, rt[b] = rvec, tvec.
 // sweep = 0: block b owns frame b, then helps with published work items; sweep = 1: published work items only.
-__global__ __launch_bounds__(PR_THREADS) void k_pnp_ransac(PnpArgs a, int sweep)
+// disable_tail_calls: a call the optimiser has marked as a possible tail call keeps its callee on the standard
+// calling convention, under which solve_hypothesis would save and restore every callee-saved register it touches --
+// some 330 stores and 330 loads of a wave's private memory per call, about 19 us.  Without the mark the compiler sees
+// that the function is local and all its callers known, and saves only what the caller has live across the call.
+__global__ __launch_bounds__(PR_THREADS) __attribute__((disable_tail_calls)) void k_pnp_ransac(PnpArgs a, int sweep)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     PrShared &S = *reinterpret_cast<PrShared *>(s_dyn);
