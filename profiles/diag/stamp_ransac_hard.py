@@ -85,6 +85,15 @@ def main():
             nb = min(256, S * F)
             print("PnP null vector by block:", (t[:nb, 8] - t[:nb, 7]).tolist())
             print("PnP start by block:", (t[:nb, 0] - t[:nb, 0].min()).tolist())
+        if hasattr(raw, "vo_debug_pnp_lm"):
+            lm = np.zeros((256, 8), np.uint64)
+            raw.vo_debug_pnp_lm.argtypes = [C.c_void_p]
+            assert raw.vo_debug_pnp_lm(lm.ctypes.data) == 0
+            lm = lm[:min(256, S * F)].astype(np.int64)
+            print("PnP LM: iterations median %d max %d, lambda steps median %d; cycles (median) sums %d, reduction %d, "
+                  "6x6 solves %d, error evaluations %d" % (np.median(lm[:, 0]), lm[:, 0].max(), np.median(lm[:, 5]),
+                                                           np.median(lm[:, 1]), np.median(lm[:, 2]), np.median(lm[:, 3]),
+                                                           np.median(lm[:, 4])))
         if hasattr(raw, "vo_debug_pnp_blocks"):
             pb = np.zeros((1024, 8), np.uint64)
             raw.vo_debug_pnp_blocks.argtypes = [C.c_void_p]

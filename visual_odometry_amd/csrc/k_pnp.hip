@@ -264,11 +264,13 @@ __device__ __forceinline__ void lstsq6_pad5(const double *Ain, const double *bin
     }
 }
 
-// 6x6 symmetric positive definite solve (Gaussian elimination, no pivoting)
+// 6x6 symmetric positive definite solve (Gaussian elimination, no pivoting).  One division per pivot: rows are
+// scaled by the pivot's reciprocal.  (Only the pose refinement uses it, which is compared to a tolerance.)
 __device__ __forceinline__ bool solve_spd6(const double *Ain, const double *bin, double *x)
 {
+#pragma clang fp contract(fast)
     constexpr int n = 6;
-    double A[36], b[6];
+    double A[36], b[6], ip[6];
 #pragma unroll
     for (int i = 0; i < 36; i++) A[i] = Ain[i];
 #pragma unroll
@@ -277,9 +279,10 @@ __device__ __forceinline__ bool solve_spd6(const double *Ain, const double *bin,
 #pragma unroll
     for (int k = 0; k < n; k++) {
         ok = ok && (A[k * n + k] != 0);
+        ip[k] = 1.0 / A[k * n + k];
 #pragma unroll
         for (int i = k + 1; i < n; i++) {
-            const double f = A[i * n + k] / A[k * n + k];
+            const double f = A[i * n + k] * ip[k];
 #pragma unroll
             for (int j = k; j < n; j++) A[i * n + j] -= f * A[k * n + j];
             b[i] -= f * b[k];
@@ -290,7 +293,7 @@ __device__ __forceinline__ bool solve_spd6(const double *Ain, const double *bin,
         double s = b[k];
 #pragma unroll
         for (int j = k + 1; j < n; j++) s -= A[k * n + j] * x[j];
-        x[k] = s / A[k * n + k];
+        x[k] = s * ip[k];
     }
     return ok;
 }
@@ -1377,7 +1380,33 @@ extern "C" int vo_debug_pnp_blocks(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_blocks), sizeof(unsigned long long) * 1024 * 8);
 }
+// Levenberg-Marquardt loop of the first 256 blocks: iterations, then cycles spent in the normal equations' sums,
+// their reduction, the 6 x 6 solves, the error evaluations; inner (lambda) steps
+__device__ unsigned long long g_pnp_lm[256 * 8];
+#define PNP_LM_T0() unsigned long long lm_t0 = __builtin_amdgcn_s_memtime()
+#define PNP_LM_LAP(i)                                                                    \
+    do {                                                                                 \
+        const unsigned long long lm_t1 = __builtin_amdgcn_s_memtime();                   \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_pnp_lm[blockIdx.x * 8 + (i)] += lm_t1 - lm_t0; \
+        lm_t0 = lm_t1;                                                                   \
+    } while (0)
+#define PNP_LM_SET(i, v)                                                                 \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_pnp_lm[blockIdx.x * 8 + (i)] = (v); \
+    } while (0)
+#define PNP_LM_COUNT(i)                                                                  \
+    do {                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_pnp_lm[blockIdx.x * 8 + (i)] += 1;  \
+    } while (0)
+extern "C" int vo_debug_pnp_lm(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pnp_lm), sizeof(unsigned long long) * 256 * 8);
+}
 #else
+#define PNP_LM_T0() do { } while (0)
+#define PNP_LM_LAP(i) do { } while (0)
+#define PNP_LM_SET(i, v) do { } while (0)
+#define PNP_LM_COUNT(i) do { } while (0)
 #define PNP_STAMP(i) do { } while (0)
 #define PNP_BLOCK(i, v) do { } while (0)
 #define PNP_BLOCK_ADD(i, v) do { } while (0)
@@ -1832,6 +1861,8 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
         const double LOG10 = log(10.);
         double prevErrNorm = DBL_MAX, errNorm = 0;
         int lambdaLg10 = -3, iters = 0;
+        for (int j = 0; j < 8; j++) PNP_LM_SET(j, 0);
+        PNP_LM_T0();
         for (;;) {
             // J^T J (upper triangle), J^T e, |e|^2 at S.param
             constexpr int NLM = 21 + 6 + 1;
@@ -1843,6 +1874,9 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                 for (int j = 0; j < 6; j++) p[j] = S.param[j];
                 rodrigues_v2m(p, R, dRdr);
                 for (int i = tid; i < n; i += PR_THREADS) {
+                    // (the refinement is compared with its CPU counterpart to a tolerance, not bit by bit: the block's
+                    // sums are paired differently anyway.  Its multiply-adds may fuse.)
+#pragma clang fp contract(fast)
                     if (!msk[i]) continue;
                     const double M[3] = {obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]};
                     const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + p[3];
@@ -1873,7 +1907,9 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                     acc[27] += e0 * e0 + e1 * e1;
                 }
             }
+            PNP_LM_LAP(1);
             block_reduce<NLM>(S, acc);
+            PNP_LM_LAP(2);
             if (tid < 6) S.prev[tid] = S.param[tid];
             if (iters == 0) prevErrNorm = sqrt(S.sums[27]);
             double JtJ[36], JtErr[6];
@@ -1903,12 +1939,15 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                     for (int a = 0; a < 6; a++) S.param[a] = S.prev[a] - dx[a];
                 }
                 __syncthreads();
+                PNP_LM_LAP(3);
+                PNP_LM_COUNT(5);
                 double e2[1] = {0};
                 {
                     double R[9], p[6];
                     for (int j = 0; j < 6; j++) p[j] = S.param[j];
                     rodrigues_v2m(p, R, nullptr);
                     for (int i = tid; i < n; i += PR_THREADS) {
+#pragma clang fp contract(fast)
                         if (!msk[i]) continue;
                         const double M[3] = {obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]};
                         const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + p[3];
@@ -1923,6 +1962,7 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                 block_reduce<1>(S, e2);
                 errNorm = sqrt(S.sums[0]);
                 __syncthreads();
+                PNP_LM_LAP(4);
                 if (errNorm > prevErrNorm) {
                     if (++lambdaLg10 <= 16) continue;
                 }
@@ -1934,6 +1974,7 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                 dn += (S.param[a] - S.prev[a]) * (S.param[a] - S.prev[a]);
                 pn += S.prev[a] * S.prev[a];
             }
+            PNP_LM_COUNT(0);
             if (++iters >= max_iter || sqrt(dn) / sqrt(pn) < eps) break;
             prevErrNorm = errNorm;
             __syncthreads();
