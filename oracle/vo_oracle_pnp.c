@@ -235,9 +235,9 @@ static void smallest_eigvec_n(const double *A, int n, double *x)
             y[i] = v;
         }
         for (int i = 0; i < n; i++) y[i] *= invD[i];
-        for (int i = n - 1; i >= 0; i--) {     /* L^T y = z */
+        for (int i = n - 1; i >= 0; i--) {     /* L^T y = z; terms taken from the last row up */
             double v = y[i];
-            for (int k = i + 1; k < n; k++) v -= Lf[k * n + i] * y[k];
+            for (int k = n - 1; k > i; k--) v -= Lf[k * n + i] * y[k];
             y[i] = v;
         }
         double nrm = 0;

@@ -829,71 +829,90 @@ __device__ void block_reduce(PrShared &S, double (&v)[NV])
 // cvFindExtrinsicCameraParams2 (cv::solvePnP, SOLVEPNP_ITERATIVE)
 // ---------------------------------------------------------------------
 
-// Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite N x N matrix (row-major)
-// by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system of
-// the pose refinement (N = 12) and the normalised DLT of the homography (N = 9) have one eigenvalue far below the
-// others (the solution, at the noise level; exactly zero for four points), so the iteration converges in a few
-// steps.  One lane, everything unrolled into registers; a tenth of the cycles of a Jacobi decomposition.  Divisions
-// by a pivot or by the norm are multiplications by its reciprocal: one division per pivot and per step instead of
-// 66 + 24 per step (a double-precision division is a dozen instructions).
-template <int N>
-__device__ __forceinline__ void smallest_eigvec(const double *A, double *x)
+// Unit eigenvector of the smallest eigenvalue of a symmetric positive semi-definite N x N matrix (row-major, in
+// LDS) by inverse iteration on its L D L^T factorisation: twelve solves from the all-ones start.  The DLT system
+// of the pose refinement (N = 12) and the normalised DLT of the homography (N = 9) have one eigenvalue far below
+// the others (the solution, at the noise level; exactly zero for four points), so the iteration converges in a few
+// steps.  Divisions by a pivot or by the norm are multiplications by its reciprocal.
+//
+// A whole wave calls; lane i < N works on row i (the other lanes follow along on copies).  The factorisation and
+// both substitutions run column by column: the value a step has just finished is broadcast from its lane and
+// every later row takes its term at once, so a step costs one multiply-subtract instead of a row's worth.  Each
+// row still subtracts its terms in the order of the one-lane loop (forward: k ascending; backward: k descending)
+// -- entries outside a row's triangle are kept at zero, and subtracting a zero product leaves a number as it is.
+// tr: N x N doubles of LDS for transposing L; x: N doubles (LDS) for the result.
+__device__ __forceinline__ double lane_value(double v, int lane)  // lane: a constant once the loops are unrolled
 {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int N>
+__device__ __forceinline__ void smallest_eigvec(const double *A, double *tr, double *x)
+{
+    const int i = threadIdx.x & 63;
+    const int row = i < N ? i : N - 1;
+    double a[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) a[k] = A[row * N + k];
     // L D L^T without pivoting; a pivot that rounding has driven to zero or below is replaced by a tiny positive
     // number: for inverse iteration that only steepens the amplification of the wanted direction
-    double Lf[N * N], D[N], invD[N];
     double dmax = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) dmax = fmax(dmax, fabs(A[i * N + i]));
+    for (int k = 0; k < N; k++) dmax = fmax(dmax, fabs(lane_value(a[k], k)));
     const double tiny = dmax * 1e-30 + 1e-300;
+    double L[N], D[N], invDi = 0;  // L[k] = L(i, k) for k < i, else 0
+#pragma unroll
+    for (int k = 0; k < N; k++) L[k] = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        double d = A[j * N + j];
+        double v = a[j];  // row j: the pivot; rows below: column j of L before scaling
 #pragma unroll
-        for (int k = 0; k < j; k++) d -= Lf[j * N + k] * Lf[j * N + k] * D[k];
+        for (int k = 0; k < j; k++) v -= L[k] * lane_value(L[k], j) * D[k];
+        double d = lane_value(v, j);
         if (!(d > tiny)) d = tiny;
         D[j] = d;
-        invD[j] = 1.0 / d;
-#pragma unroll
-        for (int i = j + 1; i < N; i++) {
-            double v = A[i * N + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) v -= Lf[i * N + k] * Lf[j * N + k] * D[k];
-            Lf[i * N + j] = v * invD[j];
-        }
+        const double inv = 1.0 / d;
+        if (i == j) invDi = inv;
+        L[j] = i > j ? v * inv : 0.0;
     }
+    // U[k] = L(k, i) for k > i, else 0: column i of L, through LDS
+    if (i < N) {
 #pragma unroll
-    for (int i = 0; i < N; i++) x[i] = 1.0 / sqrt((double)N);
+        for (int k = 0; k < N; k++) tr[i * N + k] = L[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    double U[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) U[k] = (k > i) ? tr[k * N + row] : 0.0;
+
+    double xi = 1.0 / sqrt((double)N);
     for (int it = 0; it < 12; it++) {
-        double y[N];
+        double v = xi;
 #pragma unroll
-        for (int i = 0; i < N; i++) {          // L z = x
-            double v = x[i];
+        for (int k = 0; k < N - 1; k++) v -= L[k] * lane_value(v, k);  // L z = x
+        v *= invDi;
 #pragma unroll
-            for (int k = 0; k < i; k++) v -= Lf[i * N + k] * y[k];
-            y[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < N; i++) y[i] *= invD[i];
-#pragma unroll
-        for (int i = N - 1; i >= 0; i--) {     // L^T y = z
-            double v = y[i];
-#pragma unroll
-            for (int k = i + 1; k < N; k++) v -= Lf[k * N + i] * y[k];
-            y[i] = v;
-        }
+        for (int k = N - 1; k > 0; k--) v -= U[k] * lane_value(v, k);  // L^T y = z
         double nrm = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++) nrm += y[i] * y[i];
+        for (int k = 0; k < N; k++) {
+            const double yk = lane_value(v, k);
+            nrm += yk * yk;
+        }
         nrm = sqrt(nrm);
         if (!(nrm > 0) || !isfinite(nrm)) break;
         const double inrm = 1.0 / nrm;
-#pragma unroll
-        for (int i = 0; i < N; i++) x[i] = y[i] * inrm;
+        xi = v * inrm;
     }
+    if (i < N) x[i] = xi;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
 }
-__device__ __noinline__ void smallest_eigvec12(const double *A, double *x) { smallest_eigvec<12>(A, x); }
-__device__ __noinline__ void smallest_eigvec9(const double *A, double *x) { smallest_eigvec<9>(A, x); }
+__device__ __noinline__ void smallest_eigvec12(const double *A, double *tr, double *x) { smallest_eigvec<12>(A, tr, x); }
+__device__ __noinline__ void smallest_eigvec9(const double *A, double *tr, double *x) { smallest_eigvec<9>(A, tr, x); }
 
 // 8x8 solve, Gaussian elimination with partial pivoting (the first row of largest magnitude); false when
 // singular.  One lane; every index is a compile-time constant (the row exchange is a chain of predicated
@@ -1090,12 +1109,20 @@ __device__ __noinline__ void planar_pose_init(PrShared &S, const float *obj, con
                 for (int bb = a; bb < 9; bb++, q++) acc[q] += Lx[a] * Lx[bb] + Ly[a] * Ly[bb];
         }
         block_reduce<PR_NRED>(S, acc);
+        if (tid < kWave) {  // (the hypotheses' singular vectors are not needed any more: S.vv is workspace)
+            double *LtL = &S.vv[0][0][0];
+            if (tid < 9)
+                for (int bb = 0; bb < 9; bb++) {
+                    const int lo = tid < bb ? tid : bb, hi = tid < bb ? bb : tid;
+                    LtL[tid * 9 + bb] = S.sums[lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo)];
+                }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            smallest_eigvec9(LtL, LtL + 81, S.null12);
+        }
         if (tid == 0) {
-            double LtL[81], H0[9], T[9], H[9];
-            int q = 0;
-            for (int a = 0; a < 9; a++)
-                for (int bb = a; bb < 9; bb++, q++) LtL[a * 9 + bb] = LtL[bb * 9 + a] = S.sums[q];
-            smallest_eigvec9(LtL, H0);
+            double H0[9], T[9], H[9];
+            for (int j = 0; j < 9; j++) H0[j] = S.null12[j];
             const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
             const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
             for (int i = 0; i < 3; i++)
@@ -1805,10 +1832,12 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
         }
         block_reduce<40>(S, acc);
         PNP_STAMP(7);
-        if (tid == 0) {
+        if (tid < kWave) {
             // the symmetric 12 x 12 matrix from its blocks, then the eigenvector of its smallest eigenvalue
-            double LL[144];
-            for (int row = 0; row < 12; row++)
+            // (the hypotheses' singular vectors are not needed any more: S.vv is workspace)
+            double *LL = &S.vv[0][0][0];
+            if (tid < 12) {
+                const int row = tid;
                 for (int cc = 0; cc < 12; cc++) {
                     const int br = row >> 2, bc = cc >> 2, a = row & 3, c2 = cc & 3;
                     const int lo = a < c2 ? a : c2, hi = a < c2 ? c2 : a;
@@ -1819,9 +1848,10 @@ __device__ __forceinline__ void pnp_finish(PrShared &S, const float *obj, const 
                     else if (br + bc == 3) val = S.sums[20 + q];  // blocks (1,2), (2,1)
                     LL[row * 12 + cc] = val;
                 }
-            double v[12];
-            smallest_eigvec12(LL, v);
-            for (int i = 0; i < 12; i++) S.null12[i] = v[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            smallest_eigvec12(LL, LL + 144, S.null12);
         }
         __syncthreads();
         PNP_STAMP(8);
