@@ -706,6 +706,7 @@ __device__ double epnp5_branch(const Epnp5 &e, const double *vv, const double *L
 struct PrShared {
     double vv[PR_CHUNK][4][12];  // four smallest singular vectors per hypothesis
     double model[PR_CHUNK][6];   // rvec, tvec per hypothesis
+    double model_R[PR_CHUNK][9];  // the rotation matrix of that rvec (what the scoring projects with)
     double best[6];
     double red[PR_WAVES][PR_NRED];
     double sums[PR_NRED];
@@ -1527,6 +1528,12 @@ static __device__ __noinline__ void solve_hypothesis(PrShared &S, const float *o
             rodrigues_m2v(R, rv);
 #pragma unroll
             for (int i = 0; i < 3; i++) { S.model[h][i] = rv[i]; S.model[h][3 + i] = t[i]; }
+            // the scoring projects with the matrix of the rotation vector, not with R itself: formed here, where the
+            // hypotheses of a wave do it side by side, rather than one after the other in the scoring loop
+            double Rv[9];
+            rodrigues_v2m(rv, Rv, nullptr);
+#pragma unroll
+            for (int i = 0; i < 9; i++) S.model_R[h][i] = Rv[i];
         }
         S.ok[h] = good ? 1 : 0;
     }
@@ -1658,16 +1665,39 @@ __device__ __forceinline__ void pnp_solve_score(PrShared &S, const float *obj, c
     if (wave * per_wave < nc) solve_hypothesis(S, obj, img, wave * per_wave, per_wave, nc, fx, fy, cx, cy);
     __syncthreads();
     PNP_STAMP(3);
-    for (int h = wave; h < nc; h += PR_WAVES) {
-        if (!S.ok[h]) continue;
-        double R[9];
-        rodrigues_v2m(S.model[h], R, nullptr);
-        const double t[3] = {S.model[h][3], S.model[h][4], S.model[h][5]};
-        int cnt = 0;
-        for (int i = lane; i < n; i += kWave)
-            cnt += (pnp_error(obj + 3 * i, img + 2 * i, R, t, fx, fy, cx, cy) <= thr2);
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0) S.counts[h] = cnt;
+    // a wave scores hypotheses wave, wave + PR_WAVES, ...: four at a time against each point (the projection of a
+    // point is one long dependent chain, its division above all; four of them side by side fill each other's waits)
+    for (int h0 = wave; h0 < nc; h0 += 4 * PR_WAVES) {
+        double R[4][9], t[4][3];
+        int cnt[4];
+        bool use[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int h = h0 + j * PR_WAVES;
+            use[j] = h < nc && S.ok[h];
+            const int hh = h < nc ? h : h0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[j][i] = S.model_R[hh][i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) t[j][i] = S.model[hh][3 + i];
+            cnt[j] = 0;
+        }
+        if (use[1] || use[2] || use[3]) {
+            for (int i = lane; i < n; i += kWave) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    cnt[j] += (pnp_error(obj + 3 * i, img + 2 * i, R[j], t[j], fx, fy, cx, cy) <= thr2);
+            }
+        } else if (use[0]) {
+            for (int i = lane; i < n; i += kWave)
+                cnt[0] += (pnp_error(obj + 3 * i, img + 2 * i, R[0], t[0], fx, fy, cx, cy) <= thr2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int c = cnt[j];
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            if (lane == 0 && use[j]) S.counts[h0 + j * PR_WAVES] = c;
+        }
     }
     __syncthreads();
 }
