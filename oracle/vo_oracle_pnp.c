@@ -82,9 +82,18 @@ static void jacobi_eig_desc(const double *Ain, int n, double *w, double *Vt)
             for (int q = p + 1; q < n; q++) {
                 double apq = A[p * n + q];
                 if (fabs(apq) < 1e-300) continue;
-                double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                double c = 1 / sqrt(t * t + 1), s = t * c;
+                /* tan and cos of the rotation angle as in svd12_onesided: d = a_qq - a_pp, h = 2 a_pq,
+                 * r = sqrt(d^2 + h^2), tan = sign(d) h / (|d| + r), cos^2 = (|d| + r) / (2 r), both from the one
+                 * reciprocal 1 / (2 r (|d| + r)) */
+                double d = A[q * n + q] - A[p * n + p], h = 2 * apq;
+                double x = d * d + h * h;
+                if (!(x > 0)) continue;  /* (both underflowed) */
+                double rr = sqrt(x);
+                double den = fabs(d) + rr, r2 = 2 * rr;
+                double wr = 1.0 / (r2 * den);
+                double sh = d < 0 ? -h : h;
+                double t = (sh * r2) * wr;
+                double c = sqrt((den * den) * wr), s = t * c;
                 for (int k = 0; k < n; k++) {
                     double akp = A[k * n + p], akq = A[k * n + q];
                     A[k * n + p] = c * akp - s * akq;

@@ -49,6 +49,23 @@ __device__ __forceinline__ double dist2(const double *a, const double *b)
     return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
 }
 
+// sqrt(x) for x well inside the normal range (the callers: sums of squares that a test has found to be far from
+// zero, or a squared cosine).  The reciprocal-square-root estimate refined by the two coupled Newton steps and the
+// residual corrections that yield the correctly rounded root -- the compiler's own expansion of sqrt() without the
+// rescaling of tiny arguments and the pass-through of 0 and infinity, which cannot occur here.
+__device__ __forceinline__ double sqrt_normal(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    return fma(e, h, g);
+}
+
 // cyclic Jacobi eigen-decomposition of a symmetric 3x3 matrix; eigenvalues
 // descending in w, row i of Vt the matching eigenvector
 __device__ __forceinline__ void eig3_desc(const double *Ain, double *w, double *Vt)
@@ -73,9 +90,19 @@ __device__ __forceinline__ void eig3_desc(const double *Ain, double *w, double *
             for (int q = p + 1; q < N; q++) {
                 const double apq = A[p * N + q];
                 if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q * N + q] - A[p * N + p]) / (2 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                // tan and cos of the rotation angle as in group_svd12: d = a_qq - a_pp, h = 2 a_pq,
+                // r = sqrt(d^2 + h^2), tan = sign(d) h / (|d| + r), cos^2 = (|d| + r) / (2 r), both from the one
+                // reciprocal 1 / (2 r (|d| + r)) -- square root, reciprocal, square root in a row instead of two
+                // divisions and a square root more
+                const double d = A[q * N + q] - A[p * N + p], h = 2 * apq;
+                const double x = d * d + h * h;
+                if (!(x > 0)) continue;  // (both underflowed)
+                const double rr = x > 1e-200 ? sqrt_normal(x) : sqrt(x);
+                const double den = fabs(d) + rr, r2 = 2 * rr;
+                const double wr = 1.0 / (r2 * den);
+                const double sh = d < 0 ? -h : h;
+                const double t = (sh * r2) * wr;
+                const double c = sqrt_normal((den * den) * wr), s = t * c;
 #pragma unroll
                 for (int k = 0; k < N; k++) {
                     const double akp = A[k * N + p], akq = A[k * N + q];
@@ -381,23 +408,6 @@ __device__ __forceinline__ int rr_partner(int x, int r)
     if (x == r) return 11;
     int y = (2 * r - x) % 11;
     return y < 0 ? y + 11 : y;
-}
-
-// sqrt(x) for x well inside the normal range (here: sums of squares of matrix entries that the rotation test has
-// found to be far from zero).  The reciprocal-square-root estimate refined by the two coupled Newton steps and the
-// residual corrections that yield the correctly rounded root -- the compiler's own expansion of sqrt() without the
-// rescaling of tiny arguments and the pass-through of 0 and infinity, which cannot occur here.
-__device__ __forceinline__ double sqrt_normal(double x)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = y * 0.5;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    double e = fma(-g, g, x);
-    g = fma(e, h, g);
-    e = fma(-g, g, x);
-    return fma(e, h, g);
 }
 
 // Right singular vectors of a ROWS x 12 matrix whose column gl lives in
