@@ -327,89 +327,66 @@ def main():
     if args.host_fed and world == 1:
         hs = min(S, 8)                       # streams of the host-fed launches (keeps the pinned buffers below 1 GB)
         hb = hs * F
-        fp_ = torch.from_numpy(frames_h[:hb]).pin_memory()
-        dp_ = torch.from_numpy(depth_h[:hb]).pin_memory()
-        bufs = [(torch.empty_like(fp_, device="cuda"), torch.empty_like(dp_, device="cuda")) for _ in range(2)]
-        hctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=hb)
-        hctx.set_matcher(args.matcher)
-        hctx.batch_configure(W, H, C, n_streams=hs, frames_per_stream=F, max_features=args.features,
-                             fast_threshold=20, camera=K, orb_levels=levels)
+        n_h = max(4, args.steps // 2)
         copy_stream = torch.cuda.Stream()
 
-        def upload(k):
-            with torch.cuda.stream(copy_stream):
-                bufs[k % 2][0].copy_(fp_, non_blocking=True)
-                bufs[k % 2][1].copy_(dp_, non_blocking=True)
+        def host_fed_rate(fh, dh, channels, depth16, upload_depth):
+            """frames/s of n_h launches of hb frames whose planes start in pinned host memory.  The frames of launch
+            k+1 go up on a copy stream under the kernels of launch k.  The depth planes either go up with them
+            (upload_depth) or stay where they are: the library reads the few hundred depth values a frame needs out
+            of pinned host memory itself."""
+            fp_ = torch.from_numpy(fh).pin_memory()
+            dp_ = torch.from_numpy(dh).pin_memory()
+            bufs = [(torch.empty_like(fp_, device="cuda"), torch.empty_like(dp_, device="cuda") if upload_depth else None)
+                    for _ in range(2)]
+            hctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=hb)
+            hctx.set_matcher(args.matcher)
+            hctx.batch_configure(W, H, channels, n_streams=hs, frames_per_stream=F, max_features=args.features,
+                                 fast_threshold=20, camera=K, orb_levels=levels)
 
-        def run_launch(k):
-            fb, db = bufs[k % 2]
-            hctx.batch_submit_ptr(fb.data_ptr(), W * C, W * C * H, db.data_ptr(), W, W * H)
+            def upload(k):
+                with torch.cuda.stream(copy_stream):
+                    bufs[k % 2][0].copy_(fp_, non_blocking=True)
+                    if upload_depth:
+                        bufs[k % 2][1].copy_(dp_, non_blocking=True)
 
-        n_h = max(4, args.steps // 2)
-        upload(0)
-        copy_stream.synchronize()
-        run_launch(0); upload(1); hctx.batch_wait(); copy_stream.synchronize()   # warm-up
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(1, n_h + 1):
-            run_launch(k)          # kernels of launch k ...
-            upload(k + 1)          # ... while launch k+1 comes up over PCIe
-            hres = hctx.batch_wait()
+            def run_launch(k):
+                fb, db = bufs[k % 2]
+                hctx.batch_submit_ptr(fb.data_ptr(), W * channels, W * channels * H,
+                                      db.data_ptr() if upload_depth else dp_.data_ptr(), W, W * H, depth16=depth16)
+
+            upload(0)
             copy_stream.synchronize()
-        torch.cuda.synchronize()
-        dt_h = time.perf_counter() - t0
-        bytes_per_launch = fp_.numel() + 4 * dp_.numel()
-        host_fed = {"value": hb * n_h / dt_h, "unit": "frames/s", "frames_per_launch": hb, "launches": n_h,
-                    "pcie_gb_per_s": bytes_per_launch * n_h / dt_h / 1e9,
-                    "bytes_per_frame": bytes_per_launch // hb,
-                    "how": "BGRA + float32 depth from pinned host memory, double-buffered: the upload of the next "
-                           "launch overlaps the kernels of the current one",
-                    "pose_success_rate": float(hres["pnp_success"].mean())}
-        hctx.close()
-        del bufs, fp_, dp_
+            run_launch(0); upload(1); hctx.batch_wait(); copy_stream.synchronize()   # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(1, n_h + 1):
+                run_launch(k)          # kernels of launch k ...
+                upload(k + 1)          # ... while launch k+1 comes up over PCIe
+                hres = hctx.batch_wait()
+                copy_stream.synchronize()
+            torch.cuda.synchronize()
+            dt_h = time.perf_counter() - t0
+            moved = fp_.numel() * fp_.element_size() + (dp_.numel() * dp_.element_size() if upload_depth else 0)
+            hctx.close()
+            return {"value": hb * n_h / dt_h, "unit": "frames/s", "pcie_gb_per_s": moved * n_h / dt_h / 1e9,
+                    "bytes_per_frame": moved // hb, "pose_success_rate": float(hres["pnp_success"].mean())}
 
+        host_fed = host_fed_rate(frames_h[:hb], depth_h[:hb], C, False, False)
+        host_fed.update({"frames_per_launch": hb, "launches": n_h,
+                         "how": "BGRA frames + float32 depth in pinned host memory, double-buffered: the frames of the "
+                                "next launch go up under the kernels of the current one; the depth planes are not "
+                                "uploaded (the back-projection reads its values in place over the link)"})
+        host_fed["depth_uploaded"] = host_fed_rate(frames_h[:hb], depth_h[:hb], C, False, True)
         # The same with the compact input format (an extension of this library, vo_batch_submit_depth16): gray 8-bit
-        # frames and 16-bit millimetre depth, 3 bytes per pixel over the link instead of 8
+        # frames and 16-bit millimetre depth, 3 bytes per pixel instead of 8
         gray_h = np.stack([ctx.gray(fr) for fr in frames_h[:hb]])
-        d16_h = np.clip(np.rint(depth_h[:hb]), 0, 65535).astype(np.uint16)
-        gp_ = torch.from_numpy(gray_h).pin_memory()
-        zp_ = torch.from_numpy(d16_h.view(np.int16)).pin_memory()
-        bufs = [(torch.empty_like(gp_, device="cuda"), torch.empty_like(zp_, device="cuda")) for _ in range(2)]
-        gctx = capi.Context(device=local_rank, max_width=W, max_height=H, max_features=cap, max_batch=hb)
-        gctx.set_matcher(args.matcher)
-        gctx.batch_configure(W, H, 1, n_streams=hs, frames_per_stream=F, max_features=args.features,
-                             fast_threshold=20, camera=K, orb_levels=levels)
-
-        def upload16(k):
-            with torch.cuda.stream(copy_stream):
-                bufs[k % 2][0].copy_(gp_, non_blocking=True)
-                bufs[k % 2][1].copy_(zp_, non_blocking=True)
-
-        def run16(k):
-            fb, db = bufs[k % 2]
-            gctx.batch_submit_ptr(fb.data_ptr(), W, W * H, db.data_ptr(), W, W * H, depth16=True)
-
-        upload16(0)
-        copy_stream.synchronize()
-        run16(0); upload16(1); gctx.batch_wait(); copy_stream.synchronize()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(1, n_h + 1):
-            run16(k)
-            upload16(k + 1)
-            gres = gctx.batch_wait()
-            copy_stream.synchronize()
-        torch.cuda.synchronize()
-        dt_g = time.perf_counter() - t0
-        bytes16 = gp_.numel() + 2 * zp_.numel()
-        host_fed["gray_depth16"] = {
-            "value": hb * n_h / dt_g, "unit": "frames/s", "pcie_gb_per_s": bytes16 * n_h / dt_g / 1e9,
-            "bytes_per_frame": bytes16 // hb,
-            "how": "gray 8-bit frames + 16-bit millimetre depth (vo_batch_submit_depth16, an extension: the "
-                   "reference's camera interface delivers BGRA + float32), same double-buffered upload",
-            "pose_success_rate": float(gres["pnp_success"].mean())}
-        gctx.close()
-        del bufs, gp_, zp_
+        d16_h = np.clip(np.rint(depth_h[:hb]), 0, 65535).astype(np.uint16).view(np.int16)
+        host_fed["gray_depth16"] = host_fed_rate(gray_h, d16_h, 1, True, False)
+        host_fed["gray_depth16"]["how"] = ("gray 8-bit frames + 16-bit millimetre depth (vo_batch_submit_depth16, an "
+                                           "extension: the reference's camera interface delivers BGRA + float32), "
+                                           "depth read in place")
+        host_fed["gray_depth16"]["depth_uploaded"] = host_fed_rate(gray_h, d16_h, 1, True, True)
 
     # and on a flat wall (no depth relief at all): every PnP inlier set is planar, so the pose refinement starts from
     # a homography instead of the DLT

@@ -378,8 +378,13 @@ int vo_batch_set_previous(vo_ctx *ctx, int stream, const vo_kp *kps,
                           const uint8_t *desc, int n);
 /* Enqueue one batch. frames: batch x height x row_stride bytes, consecutive
  * frames frame_stride bytes apart; depth (may be NULL): float32 mm, strides
- * in elements.  Device pointers are read in place; host pointers are copied
- * to the device first.  Returns without waiting for the GPU. */
+ * in elements.  Device pointers are read in place; host frames are copied
+ * to the device first.  A depth plane in host memory is not copied: the
+ * back-projection fetches the few hundred values it needs over the link, from
+ * the caller's buffer when that is pinned (vo_host_alloc, hipHostMalloc,
+ * hipHostRegister), else from a pinned copy the call makes.  Buffers handed
+ * over must stay as they are until vo_batch_wait has returned.  Returns without
+ * waiting for the GPU. */
 int vo_batch_submit(vo_ctx *ctx, const uint8_t *frames, int row_stride,
                     size_t frame_stride, const float *depth,
                     int depth_row_stride, size_t depth_frame_stride);

@@ -278,3 +278,70 @@ def test_padded_host_planes_in_ordinary_memory(ctx, F):
                         "inliers": ctx.batch_inliers(b) if res["pnp_success"][b] else np.zeros(0, np.int32),
                         "result": res[b].copy()})
     _same(out, ref)
+
+
+@pytest.mark.parametrize("depth16", [False, True])
+def test_depth_read_in_place_from_pinned_host_memory(ctx, depth16):
+    """Frames already on the device, depth planes left in pinned host memory with padded rows and planes (what a
+    host-fed pipeline does that uploads frames itself): the back-projection reads the depth values where they lie.
+    Same results as with the depth planes on the device."""
+    from visual_odometry_amd import capi
+    lib = capi.load()
+    hip = C.CDLL("libamdhip64.so.7")   # (the runtime the library itself is linked to)
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def to_device(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0   # hipMemcpyHostToDevice
+        return p
+
+    cam = synth.CONFIG_CAMERAS["hd720"]
+    F = 3
+    seqs = [synth.make_sequence(cam, 2 * F, seed=4800, channels=4)]
+    K = (cam.fx, cam.fy, cam.cx, cam.cy)
+    esz = 2 if depth16 else 4
+    drow = cam.width + 24
+    dplane = drow * cam.height + 136
+    pd = lib.vo_host_alloc(F * dplane * esz)
+    assert pd
+    try:
+        host = np.ctypeslib.as_array(((C.c_uint16 if depth16 else C.c_float) * (F * dplane)).from_address(pd))
+        runs = []
+        for in_place in (False, True):
+            ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=F, max_features=600,
+                                fast_threshold=20, camera=K, orb_levels=0)
+            ctx.batch_set_packed_output(False)
+            ctx.batch_set_graph(False)
+            out = []
+            for nb in range(2):
+                frames = np.stack([seqs[0]["frames"][nb * F + f] for f in range(F)])
+                depth = np.stack([seqs[0]["depth"][nb * F + f] for f in range(F)])
+                if depth16:
+                    depth = np.clip(np.rint(depth), 0, 65535).astype(np.uint16)
+                host[:] = 7 if depth16 else 123.0   # garbage in the padding (valid-looking depth values)
+                for f in range(F):
+                    host[f * dplane:f * dplane + drow * cam.height].reshape(cam.height, drow)[:, :cam.width] = depth[f]
+                fd = to_device(np.ascontiguousarray(frames))
+                dd = None if in_place else to_device(host)
+                ctx.batch_submit_ptr(fd.value, cam.width * 4, cam.width * 4 * cam.height, pd if in_place else dd.value,
+                                     drow, dplane, depth16=depth16)
+                res = ctx.batch_wait()
+                hip.hipFree(fd)
+                if dd is not None:
+                    hip.hipFree(dd)
+                for b in range(F):
+                    k, d = ctx.batch_features(b)
+                    m, _ = ctx.batch_matches(b, 0)
+                    t, _ = ctx.batch_matches(b, 1)
+                    v, p3 = ctx.batch_matches(b, 2)
+                    out.append({"kps": k, "desc": d, "matches": m, "tracked": t, "valid": v, "pts3": p3,
+                                "inliers": ctx.batch_inliers(b) if res["pnp_success"][b] else np.zeros(0, np.int32),
+                                "result": res[b].copy()})
+            runs.append(out)
+        assert sum(int(r["result"]["pnp_success"]) for r in runs[0]) >= 2 * F - 2   # (poses were computed)
+        _same(runs[1], runs[0])
+    finally:
+        lib.vo_host_free(pd)

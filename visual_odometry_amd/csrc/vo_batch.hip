@@ -376,7 +376,7 @@ int vo_ctx::stager_send(StageJob &j, bool block)
             __builtin_ia32_pause();
         }
         const size_t off = (size_t)ch * StageJob::kChunk, len = std::min(StageJob::kChunk, j.total - off);
-        if (j.err == 0) {
+        if (j.err == 0 && j.dst) {  // (no destination: the plane is read where it has been packed)
             const hipError_t e = hipMemcpyAsync(j.dst + off, j.stage + off, len, hipMemcpyHostToDevice, j.stream);
             if (e != hipSuccess) j.err = (int)e;
         }
@@ -557,6 +557,21 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
             for (int k = 0; k < n; k++) (void)c->stager_work(c->stager.jobs[k], true);
         }
     } pool{c};
+    // A depth plane in host memory is not uploaded at all when the GPU can read it where it lies: the back-projection
+    // wants one value per tracked key point, a few hundred per frame, which it fetches over the link -- from the
+    // caller's buffer if that is pinned, else from the pinned staging area the plane has been packed into.  (That is
+    // half of the bytes of a BGRA + float32-depth frame off the link, and no second stream to wait for.)
+    // VO_DEPTH_IN_PLACE=0: upload it as before (for comparisons).
+    static const bool in_place_on = !(getenv("VO_DEPTH_IN_PLACE") && getenv("VO_DEPTH_IN_PLACE")[0] == '0');
+    const float *depth_view = nullptr;  // device address of the host plane(s)
+    if (depth_host_mem && in_place_on && (!stage_depth || pool_depth)) {
+        void *dp = nullptr;
+        void *hp = stage_depth ? static_cast<void *>(stage + 2 * frames_bytes)
+                               : const_cast<void *>(static_cast<const void *>(depth));
+        if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) depth_view = static_cast<const float *>(dp);
+        else (void)hipGetLastError();
+    }
+    const bool depth_in_place = depth_view != nullptr;
     int job_frames = -1, job_depth = -1;
     if (pool_frames || pool_depth) {
         vo_ctx::StagePool &w = c->stager;
@@ -583,7 +598,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
         }
         if (pool_depth) {
             fill(w.jobs[n], reinterpret_cast<const uint8_t *>(depth), stage + 2 * frames_bytes,
-                 reinterpret_cast<uint8_t *>(c->d_depth), dsz * b.width, dsz * (size_t)depth_row_stride,
+                 depth_in_place ? nullptr : reinterpret_cast<uint8_t *>(c->d_depth), dsz * b.width,
+                 dsz * (size_t)depth_row_stride,
                  dsz * depth_frame_stride, c->copy_stream);
             job_depth = n++;
         }
@@ -617,7 +633,13 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     const float *depth_host = depth;
     const int depth_row_stride_host = depth_row_stride;
     const size_t depth_frame_stride_host = depth_frame_stride;
-    if (depth_from_host) {
+    if (depth_in_place) {
+        dsrc = depth_view;
+        if (stage_depth) {  // packed planes
+            depth_row_stride = b.width;
+            depth_frame_stride = (size_t)b.width * b.height;
+        }
+    } else if (depth_from_host) {
         c->depth_planes_nan = false;
         dsrc = c->d_depth;
         depth_row_stride = b.width;
@@ -627,8 +649,8 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     // Pinned depth: the copy is queued before any kernel is launched, behind the frames' copy (two copies at once
     // would share the link and delay the frames, which everything waits for).  Ordinary memory: the copy call
     // keeps this thread busy, so it is made after the first part of the chain has been launched.
-    const bool depth_early = depth_from_host && !stage_depth;
-    const bool depth_late = depth_from_host && !depth_early && !pool_depth;
+    const bool depth_early = depth_from_host && !depth_in_place && !stage_depth;
+    const bool depth_late = depth_from_host && !depth_in_place && !depth_early && !pool_depth;
     auto upload_depth = [&]() -> int {
         if (frames_from_host) {
             HIP_TRY(c, hipEventRecord(c->ev_frames, c->stream));
@@ -795,9 +817,10 @@ static int batch_submit(vo_ctx *c, const uint8_t *frames, int row_stride, size_t
     if (pool_depth) {
         const hipError_t he = (hipError_t)c->stager_work(c->stager.jobs[job_depth], true);
         if (he != hipSuccess) return bfail(c, VO_ERR_HIP, "vo_batch_submit: depth upload: %s", hipGetErrorString(he));
-        HIP_TRY(c, hipEventRecord(c->ev_depth, c->copy_stream));
+        // (read in place: the plane is complete in pinned memory before the kernels that read it are launched)
+        if (!depth_in_place) HIP_TRY(c, hipEventRecord(c->ev_depth, c->copy_stream));
     }
-    if (depth_from_host) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_depth, 0));
+    if (depth_from_host && !depth_in_place) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_depth, 0));
     if (c->use_graph) {
         HIP_TRY(c, hipGraphLaunch(c->graph_exec_back, c->stream));
     } else {
