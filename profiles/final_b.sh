@@ -10,6 +10,7 @@ timeout -k 10 200 python3 bench.py --matcher popcount --cpu-frames 0 --cpu-worke
 cat gpurun_out/${TAG}_bench_orb.json gpurun_out/${TAG}_bench_fast.json gpurun_out/${TAG}_bench_orb_popcount.json > gpurun_out/${TAG}_bench_lines.jsonl
 timeout -k 10 300 python3 tools/bench_configs.py > gpurun_out/${TAG}_secondary_configs.jsonl 2> gpurun_out/${TAG}_configs.err
 timeout -k 10 400 python3 -u tools/lat_stage_ab.py > gpurun_out/${TAG}_latency_staging_ab.txt 2>&1
+timeout -k 10 300 python3 -u tools/lat_depth_ab.py > gpurun_out/${TAG}_depth_in_place_ab.txt 2>&1
 python3 - <<PY
 import json
 for l in open("gpurun_out/${TAG}_bench_lines.jsonl"):

@@ -1,7 +1,8 @@
-"""Single-stream latency through the C++ facade and the host-fed rate with the depth plane read in place
-(VO_DEPTH_IN_PLACE unset) or uploaded (VO_DEPTH_IN_PLACE=0).  GPU box; every configuration runs in a child
-process of its own (the switch is read once per process)."""
-import json, os, subprocess, sys
+"""Single-stream latency through the C++ facade with the depth plane read in place (VO_DEPTH_IN_PLACE unset) or
+uploaded on a second stream (VO_DEPTH_IN_PLACE=0).  GPU box; every configuration runs in a child process of its
+own (the switch is read once per process).  (The host-fed rates of both arrangements are on the bench line:
+host_fed_fps and host_fed_fps.depth_uploaded.)"""
+import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 if __name__ == "__main__":
     if len(sys.argv) > 1:
@@ -15,12 +16,3 @@ if __name__ == "__main__":
         for mode in ("1", "0"):
             env = dict(os.environ, VO_DEPTH_IN_PLACE=mode)
             subprocess.run([sys.executable, "-u", os.path.abspath(__file__), f"in_place {mode}"], env=env, check=True)
-    for mode in ("1", "0"):
-        env = dict(os.environ, VO_DEPTH_IN_PLACE=mode)
-        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--cpu-frames", "0", "--cpu-workers", "0",
-                              "--hard-scene", "0", "--flat-scene", "0", "--facade-latency", "0", "--steps", "20"],
-                             env=env, check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1]
-        d = json.loads(out)
-        h = d["host_fed_fps"]
-        print("in_place", mode, "host_fed", round(h["value"]), "pose", h["pose_success_rate"], "gray+depth16", round(h["gray_depth16"]["value"]),
-              "pose", h["gray_depth16"]["pose_success_rate"], flush=True)
