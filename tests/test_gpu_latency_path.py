@@ -345,3 +345,36 @@ def test_depth_read_in_place_from_pinned_host_memory(ctx, depth16):
         _same(runs[1], runs[0])
     finally:
         lib.vo_host_free(pd)
+
+
+def test_uploaded_depth_path_equals_depth_read_in_place():
+    """VO_DEPTH_IN_PLACE=0 (the arrangement a plane too large for the staging area still gets: the depth plane
+    uploaded on a second stream, the second part of the chain behind its event) returns what the default does.
+    The switch is read once per process, so each variant runs in a process of its own and prints a digest."""
+    import hashlib, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import hashlib, numpy as np\n"
+        "from visual_odometry_amd import capi, synth\n"
+        "cam = synth.CONFIG_CAMERAS['vga']\n"
+        "seq = synth.make_sequence(cam, 4, seed=4900, channels=4)\n"
+        "ctx = capi.Context(0, cam.width, cam.height, 700, 2)\n"
+        "ctx.batch_configure(cam.width, cam.height, 4, n_streams=1, frames_per_stream=2, max_features=600,\n"
+        "                    fast_threshold=20, camera=(cam.fx, cam.fy, cam.cx, cam.cy), orb_levels=0)\n"
+        "h = hashlib.sha256()\n"
+        "for nb in range(2):\n"
+        "    ctx.batch_submit(np.stack(seq['frames'][2 * nb:2 * nb + 2]), np.stack(seq['depth'][2 * nb:2 * nb + 2]))\n"
+        "    res = ctx.batch_wait()\n"
+        "    h.update(res.tobytes())\n"
+        "    for b in range(2):\n"
+        "        v, p3 = ctx.batch_matches(b, 2)\n"
+        "        h.update(v.tobytes()); h.update(p3.tobytes())\n"
+        "assert res['pnp_success'].all()\n"
+        "print('digest', h.hexdigest())\n")
+    digests = []
+    for mode in ("1", "0"):
+        env = dict(os.environ, VO_DEPTH_IN_PLACE=mode, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", prog], env=env, cwd=root, capture_output=True, text=True, timeout=110)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("digest")][-1])
+    assert digests[0] == digests[1]
