@@ -305,8 +305,9 @@ def test_depth_read_in_place_from_pinned_host_memory(ctx, depth16):
     esz = 2 if depth16 else 4
     drow = cam.width + 24
     dplane = drow * cam.height + 136
-    pd = lib.vo_host_alloc(F * dplane * esz)
-    assert pd
+    base = lib.vo_host_alloc(F * dplane * esz + 4096)
+    assert base
+    pd = base + 1280   # (the planes start inside the allocation, not at its first byte)
     try:
         host = np.ctypeslib.as_array(((C.c_uint16 if depth16 else C.c_float) * (F * dplane)).from_address(pd))
         runs = []
@@ -344,7 +345,7 @@ def test_depth_read_in_place_from_pinned_host_memory(ctx, depth16):
         assert sum(int(r["result"]["pnp_success"]) for r in runs[0]) >= 2 * F - 2   # (poses were computed)
         _same(runs[1], runs[0])
     finally:
-        lib.vo_host_free(pd)
+        lib.vo_host_free(base)
 
 
 def test_uploaded_depth_path_equals_depth_read_in_place():
